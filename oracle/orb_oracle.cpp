@@ -1,0 +1,785 @@
+// CPU oracle for the ORB extractor hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+// See orb_oracle.h for the scope, the pinned decisions and the "parity unpinned" note.
+//
+// Every function cites the reference lines (src/ORBextractor.cc unless another file is
+// named) it restates.  OpenCV primitives are restated from the published OpenCV 3.4.5
+// algorithms (the version the reference's author linked: cmake-build-debug/CMakeFiles/
+// myvideo.dir/link.txt:1); OpenCV itself is an un-vendored dependency of the reference.
+//
+// Build with -ffp-contract=off: every fused multiply-add below is an explicit fma()/fmaf().
+
+#include "orb_oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <list>
+#include <utility>
+#include <vector>
+
+namespace {
+
+const int PATCH_SIZE = 31;        // :73
+const int HALF_PATCH_SIZE = 15;   // :74
+const int EDGE_THRESHOLD = 19;    // :75
+
+const int8_t kPattern[1024] = {
+#include "../include/orb_pattern_31.inc"
+};
+
+// cvRound on x86-64 is cvtss2si / cvtsd2si under the default rounding mode: half to even.
+inline int cv_round(double v) { return (int)std::nearbyint(v); }
+inline int cv_roundf(float v) { return (int)std::nearbyintf(v); }
+
+inline int reflect101(int p, int len) {
+    if (p < 0) p = -p;
+    if (p >= len) p = 2 * len - 2 - p;
+    return p;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// Constructor arithmetic: src/ORBextractor.cc:416-494.  scaleFactor is a double member
+// initialised from a float argument (include/ORBextractor.h:98).
+extern "C" int orc_params_init(orc_params* p, int nfeatures, float scale_factor, int nlevels,
+                               int ini_th, int min_th) {
+    if (!p || nlevels < 1 || nlevels > ORC_MAX_LEVELS) return -1;
+    std::memset(p, 0, sizeof(*p));
+    p->nfeatures = nfeatures;
+    p->scale_factor = scale_factor;
+    p->nlevels = nlevels;
+    p->ini_th_fast = ini_th;
+    p->min_th_fast = min_th;
+    const double scaleFactor = (double)scale_factor;
+    p->scale[0] = 1.0f;
+    p->sigma2[0] = 1.0f;
+    for (int i = 1; i < nlevels; i++) {
+        p->scale[i] = (float)((double)p->scale[i - 1] * scaleFactor);  // :432
+        p->sigma2[i] = p->scale[i] * p->scale[i];                      // :433
+    }
+    for (int i = 0; i < nlevels; i++) {
+        p->inv_scale[i] = 1.0f / p->scale[i];    // :441
+        p->inv_sigma2[i] = 1.0f / p->sigma2[i];  // :442
+    }
+    // :448-463
+    float factor = (float)(1.0 / scaleFactor);
+    float nDesired = (float)nfeatures * (1.0f - factor) /
+                     (1.0f - (float)std::pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int level = 0; level < nlevels - 1; level++) {
+        p->quota[level] = cv_roundf(nDesired);
+        sum += p->quota[level];
+        nDesired *= factor;
+    }
+    p->quota[nlevels - 1] = std::max(nfeatures - sum, 0);
+    // :473-493
+    int v, v0;
+    int vmax = (int)std::floor(HALF_PATCH_SIZE * std::sqrt(2.f) / 2 + 1);
+    int vmin = (int)std::ceil(HALF_PATCH_SIZE * std::sqrt(2.f) / 2);
+    const double hp2 = HALF_PATCH_SIZE * HALF_PATCH_SIZE;
+    for (v = 0; v <= vmax; ++v) p->umax[v] = cv_round(std::sqrt(hp2 - v * v));
+    for (v = HALF_PATCH_SIZE, v0 = 0; v >= vmin; --v) {
+        while (p->umax[v0] == p->umax[v0 + 1]) ++v0;
+        p->umax[v] = v0;
+        ++v0;
+    }
+    return 0;
+}
+
+// Level size: :1220-1221 (float multiply, then cvRound).
+extern "C" void orc_level_size(const orc_params* p, int w0, int h0, int level, int* w, int* h) {
+    float scale = p->inv_scale[level];
+    *w = cv_roundf((float)w0 * scale);
+    *h = cv_roundf((float)h0 * scale);
+}
+
+// ---------------------------------------------------------------------------------------
+// cv::resize(src, dst, dsize, 0, 0, INTER_LINEAR) for 8UC1, OpenCV 3.4.5 fixed-point path
+// (call site :1237).  11-bit coefficients; horizontal pass into int32, vertical pass
+// ((b0*(T0>>4))>>16) + ((b1*(T1>>4))>>16) + 2) >> 2.
+extern "C" void orc_resize_linear(const uint8_t* src, int sw, int sh, int sstride,
+                                  uint8_t* dst, int dw, int dh, int dstride) {
+    const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    const double scale_x = 1.0 / inv_scale_x, scale_y = 1.0 / inv_scale_y;
+    std::vector<int> xofs(dw), yofs(dh);
+    std::vector<short> alpha(2 * (size_t)dw), beta(2 * (size_t)dh);
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)std::floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx;
+        alpha[2 * dx] = (short)cv_roundf((1.f - fx) * 2048.f);
+        alpha[2 * dx + 1] = (short)cv_roundf(fx * 2048.f);
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)std::floor(fy);
+        fy -= sy;
+        yofs[dy] = sy;
+        beta[2 * dy] = (short)cv_roundf((1.f - fy) * 2048.f);
+        beta[2 * dy + 1] = (short)cv_roundf(fy * 2048.f);
+    }
+    std::vector<int> row0(dw), row1(dw);
+    auto hresize = [&](int sy, std::vector<int>& out) {
+        const uint8_t* S = src + (size_t)sy * sstride;
+        for (int dx = 0; dx < dw; dx++) {
+            int sx = xofs[dx];
+            if (sx >= sw - 1)
+                out[dx] = S[sx] * 2048;
+            else
+                out[dx] = S[sx] * alpha[2 * dx] + S[sx + 1] * alpha[2 * dx + 1];
+        }
+    };
+    auto clip = [](int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; };
+    for (int dy = 0; dy < dh; dy++) {
+        int sy0 = clip(yofs[dy], 0, sh), sy1 = clip(yofs[dy] + 1, 0, sh);
+        hresize(sy0, row0);
+        hresize(sy1, row1);
+        int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
+        uint8_t* D = dst + (size_t)dy * dstride;
+        for (int dx = 0; dx < dw; dx++) {
+            int v = (((b0 * (row0[dx] >> 4)) >> 16) + ((b1 * (row1[dx] >> 4)) >> 16) + 2) >> 2;
+            D[dx] = (uint8_t)std::min(std::max(v, 0), 255);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// cv::GaussianBlur(m, m, Size(7,7), 2, 2, BORDER_REFLECT_101) on a continuous 8UC1 image
+// (call site :1188; the input is a clone, :1182, so the border reflects the level's own
+// pixels).  OpenCV 3.4.5 8-bit fixed-point path: taps rint(256*g) = 18,34,49,55,49,34,18.
+extern "C" void orc_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst,
+                                   int dstride) {
+    static const int K[7] = {18, 34, 49, 55, 49, 34, 18};
+    std::vector<uint16_t> tmp((size_t)w * h);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* S = src + (size_t)y * sstride;
+        uint16_t* T = &tmp[(size_t)y * w];
+        for (int x = 0; x < w; x++) {
+            unsigned s = 0;
+            if (x >= 3 && x < w - 3) {
+                for (int i = 0; i < 7; i++) s += K[i] * S[x + i - 3];
+            } else {
+                for (int i = 0; i < 7; i++) s += K[i] * S[reflect101(x + i - 3, w)];
+            }
+            T[x] = (uint16_t)s;  // <= 255*257 = 65535, exact
+        }
+    }
+    for (int y = 0; y < h; y++) {
+        const uint16_t* R[7];
+        for (int j = 0; j < 7; j++) R[j] = &tmp[(size_t)reflect101(y + j - 3, h) * w];
+        uint8_t* D = dst + (size_t)y * dstride;
+        for (int x = 0; x < w; x++) {
+            uint32_t s = 0;
+            for (int j = 0; j < 7; j++) s += (uint32_t)K[j] * R[j][x];
+            s = (s + 32768u) >> 16;
+            D[x] = (uint8_t)std::min(s, 255u);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// cv::FAST(img, kps, threshold, true): FAST-9/16 with 3x3 non-max suppression, OpenCV
+// 3.4.5 FAST_t<16> and cornerScore<16> (call sites :900, :905).
+namespace {
+
+const int kRingDx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+const int kRingDy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+
+// cornerScore<16>: d[k] = v - ring[k], k = 0..24 (cyclic).
+int corner_score16(const uint8_t* ptr, const int* pixel, int threshold) {
+    const int N = 25;
+    int v = ptr[0];
+    short d[N];
+    for (int k = 0; k < N; k++) d[k] = (short)(v - ptr[pixel[k]]);
+    int a0 = threshold;
+    for (int k = 0; k < 16; k += 2) {
+        int a = std::min((int)d[k + 1], (int)d[k + 2]);
+        a = std::min(a, (int)d[k + 3]);
+        if (a <= a0) continue;
+        a = std::min(a, (int)d[k + 4]);
+        a = std::min(a, (int)d[k + 5]);
+        a = std::min(a, (int)d[k + 6]);
+        a = std::min(a, (int)d[k + 7]);
+        a = std::min(a, (int)d[k + 8]);
+        a0 = std::max(a0, std::min(a, (int)d[k]));
+        a0 = std::max(a0, std::min(a, (int)d[k + 9]));
+    }
+    int b0 = -a0;
+    for (int k = 0; k < 16; k += 2) {
+        int b = std::max((int)d[k + 1], (int)d[k + 2]);
+        b = std::max(b, (int)d[k + 3]);
+        b = std::max(b, (int)d[k + 4]);
+        b = std::max(b, (int)d[k + 5]);
+        if (b >= b0) continue;
+        b = std::max(b, (int)d[k + 6]);
+        b = std::max(b, (int)d[k + 7]);
+        b = std::max(b, (int)d[k + 8]);
+        b0 = std::min(b0, std::max(b, (int)d[k]));
+        b0 = std::min(b0, std::max(b, (int)d[k + 9]));
+    }
+    return -b0 - 1;
+}
+
+struct FastScratch {
+    std::vector<uint8_t> score;
+};
+
+int fast9_16(const uint8_t* img, int w, int h, int stride, int threshold, orc_cand* out, int cap,
+             FastScratch& scratch) {
+    const int K = 8, N = 25;
+    int pixel[25];
+    for (int k = 0; k < 16; k++) pixel[k] = kRingDx[k] + kRingDy[k] * stride;
+    for (int k = 16; k < 25; k++) pixel[k] = pixel[k - 16];
+    threshold = std::min(std::max(threshold, 0), 255);
+    if (w < 7 || h < 7) return 0;
+    scratch.score.assign((size_t)w * h, 0);
+    uint8_t* score = scratch.score.data();
+    for (int i = 3; i < h - 3; i++) {
+        const uint8_t* row = img + (size_t)i * stride;
+        for (int j = 3; j < w - 3; j++) {
+            const uint8_t* ptr = row + j;
+            int v = ptr[0];
+            int lo = v - threshold, hi = v + threshold;
+            // quick rejection on the opposite pairs (0,8) (2,10) (4,12) (6,14) then the odd ones
+            auto cls = [&](int k) { int x = ptr[pixel[k]]; return (x < lo ? 1 : 0) | (x > hi ? 2 : 0); };
+            int d = cls(0) | cls(8);
+            if (d == 0) continue;
+            d &= cls(2) | cls(10);
+            d &= cls(4) | cls(12);
+            d &= cls(6) | cls(14);
+            if (d == 0) continue;
+            d &= cls(1) | cls(9);
+            d &= cls(3) | cls(11);
+            d &= cls(5) | cls(13);
+            d &= cls(7) | cls(15);
+            bool corner = false;
+            if (d & 1) {
+                int count = 0;
+                for (int k = 0; k < N; k++) {
+                    if (ptr[pixel[k]] < lo) {
+                        if (++count > K) { corner = true; break; }
+                    } else
+                        count = 0;
+                }
+            }
+            if (!corner && (d & 2)) {
+                int count = 0;
+                for (int k = 0; k < N; k++) {
+                    if (ptr[pixel[k]] > hi) {
+                        if (++count > K) { corner = true; break; }
+                    } else
+                        count = 0;
+                }
+            }
+            if (corner) score[(size_t)i * w + j] = (uint8_t)corner_score16(ptr, pixel, threshold);
+        }
+    }
+    // 3x3 strict non-max suppression; rows/cols outside [3, dim-3) hold score 0.
+    // A corner always has score >= threshold >= 0; score 0 corners can only arise at
+    // threshold 0 and are never strictly greater than their (zero) neighbours... except
+    // that OpenCV still tests them; with all-zero neighbours 0 > 0 is false, so they drop.
+    int n = 0;
+    for (int i = 3; i < h - 3; i++) {
+        for (int j = 3; j < w - 3; j++) {
+            const uint8_t* s = score + (size_t)i * w + j;
+            int sc = s[0];
+            if (sc == 0) continue;
+            if (sc > s[-1] && sc > s[1] && sc > s[-w - 1] && sc > s[-w] && sc > s[-w + 1] &&
+                sc > s[w - 1] && sc > s[w] && sc > s[w + 1]) {
+                if (n < cap) {
+                    out[n].x = j;
+                    out[n].y = i;
+                    out[n].response = sc;
+                }
+                n++;
+            }
+        }
+    }
+    return n;
+}
+
+}  // namespace
+
+extern "C" int orc_fast(const uint8_t* img, int w, int h, int stride, int threshold,
+                        orc_cand* out, int cap) {
+    FastScratch scratch;
+    return fast9_16(img, w, h, stride, threshold, out, cap, scratch);
+}
+
+// ComputeKeyPointsOctTree, cell-grid part: :862-920.  Output coordinates are relative to
+// (minBorderX, minBorderY) = (16,16), in (cell row, cell col, y, x) order.
+extern "C" int orc_level_candidates(const uint8_t* img, int w, int h, int stride, int ini_th,
+                                    int min_th, orc_cand* out, int cap) {
+    const float W = 30;
+    const int minBorderX = EDGE_THRESHOLD - 3, minBorderY = minBorderX;
+    const int maxBorderX = w - EDGE_THRESHOLD + 3, maxBorderY = h - EDGE_THRESHOLD + 3;
+    const float width = (float)(maxBorderX - minBorderX), height = (float)(maxBorderY - minBorderY);
+    const int nCols = (int)(width / W), nRows = (int)(height / W);
+    if (nCols < 1 || nRows < 1) return 0;  // the reference divides by zero here
+    const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
+    FastScratch scratch;
+    std::vector<orc_cand> cell((size_t)(wCell + 6) * (hCell + 6));
+    int n = 0;
+    for (int i = 0; i < nRows; i++) {
+        const float iniY = (float)(minBorderY + i * hCell);
+        float maxY = iniY + hCell + 6;
+        if (iniY >= maxBorderY - 3) continue;
+        if (maxY > maxBorderY) maxY = (float)maxBorderY;
+        for (int j = 0; j < nCols; j++) {
+            const float iniX = (float)(minBorderX + j * wCell);
+            float maxX = iniX + wCell + 6;
+            if (iniX >= maxBorderX - 6) continue;
+            if (maxX > maxBorderX) maxX = (float)maxBorderX;
+            const int x0 = (int)iniX, y0 = (int)iniY, cw = (int)maxX - x0, ch = (int)maxY - y0;
+            const uint8_t* sub = img + (size_t)y0 * stride + x0;
+            int m = fast9_16(sub, cw, ch, stride, ini_th, cell.data(), (int)cell.size(), scratch);
+            if (m == 0) m = fast9_16(sub, cw, ch, stride, min_th, cell.data(), (int)cell.size(), scratch);
+            for (int k = 0; k < m; k++) {
+                if (n < cap) {
+                    out[n].x = cell[k].x + j * wCell;
+                    out[n].y = cell[k].y + i * hCell;
+                    out[n].response = cell[k].response;
+                }
+                n++;
+            }
+        }
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------
+// DistributeOctTree (:572-852) and ExtractorNode::DivideNode (:507-570).  Points are kept as
+// indices into the candidate array.  Sort ties: decision D2 (creation sequence).
+namespace {
+
+struct Node {
+    int ULx, ULy, URx, URy, BLx, BLy, BRx, BRy;
+    std::vector<int> keys;
+    std::list<Node>::iterator lit;
+    bool bNoMore = false;
+    long seq = 0;
+};
+
+void divide_node(const Node& p, const orc_cand* c, Node& n1, Node& n2, Node& n3, Node& n4) {
+    const int halfX = (int)std::ceil((float)(p.URx - p.ULx) / 2);
+    const int halfY = (int)std::ceil((float)(p.BRy - p.ULy) / 2);
+    n1.ULx = p.ULx; n1.ULy = p.ULy;
+    n1.URx = p.ULx + halfX; n1.URy = p.ULy;
+    n1.BLx = p.ULx; n1.BLy = p.ULy + halfY;
+    n1.BRx = p.ULx + halfX; n1.BRy = p.ULy + halfY;
+    n2.ULx = n1.URx; n2.ULy = n1.URy;
+    n2.URx = p.URx; n2.URy = p.URy;
+    n2.BLx = n1.BRx; n2.BLy = n1.BRy;
+    n2.BRx = p.URx; n2.BRy = p.ULy + halfY;
+    n3.ULx = n1.BLx; n3.ULy = n1.BLy;
+    n3.URx = n1.BRx; n3.URy = n1.BRy;
+    n3.BLx = p.BLx; n3.BLy = p.BLy;
+    n3.BRx = n1.BRx; n3.BRy = p.BLy;
+    n4.ULx = n3.URx; n4.ULy = n3.URy;
+    n4.URx = n2.BRx; n4.URy = n2.BRy;
+    n4.BLx = n3.BRx; n4.BLy = n3.BRy;
+    n4.BRx = p.BRx; n4.BRy = p.BRy;
+    for (size_t i = 0; i < p.keys.size(); i++) {
+        const orc_cand& kp = c[p.keys[i]];
+        if ((float)kp.x < (float)n1.URx) {
+            if ((float)kp.y < (float)n1.BRy)
+                n1.keys.push_back(p.keys[i]);
+            else
+                n3.keys.push_back(p.keys[i]);
+        } else if ((float)kp.y < (float)n1.BRy)
+            n2.keys.push_back(p.keys[i]);
+        else
+            n4.keys.push_back(p.keys[i]);
+    }
+    if (n1.keys.size() == 1) n1.bNoMore = true;
+    if (n2.keys.size() == 1) n2.bNoMore = true;
+    if (n3.keys.size() == 1) n3.bNoMore = true;
+    if (n4.keys.size() == 1) n4.bNoMore = true;
+}
+
+}  // namespace
+
+extern "C" int orc_distribute_octree(const orc_cand* cands, int n, int minX, int maxX, int minY,
+                                     int maxY, int N, int32_t* out_idx, int cap) {
+    const int nIni = (int)std::round((float)(maxX - minX) / (maxY - minY));  // :576
+    if (nIni < 1) return -1;  // undefined behaviour in the reference (tall images)
+    const float hX = (float)(maxX - minX) / nIni;
+    std::list<Node> lNodes;
+    std::vector<Node*> vpIniNodes(nIni);
+    long seq = 0;
+    for (int i = 0; i < nIni; i++) {
+        Node ni;
+        ni.ULx = (int)(hX * (float)i); ni.ULy = 0;
+        ni.URx = (int)(hX * (float)(i + 1)); ni.URy = 0;
+        ni.BLx = ni.ULx; ni.BLy = maxY - minY;
+        ni.BRx = ni.URx; ni.BRy = maxY - minY;
+        ni.seq = seq++;
+        lNodes.push_back(ni);
+        vpIniNodes[i] = &lNodes.back();
+    }
+    for (int i = 0; i < n; i++) {
+        int r = (int)((float)cands[i].x / hX);  // :620
+        if (r < 0 || r >= nIni) return -2;      // out-of-range write in the reference
+        vpIniNodes[r]->keys.push_back(i);
+    }
+    std::list<Node>::iterator lit = lNodes.begin();
+    while (lit != lNodes.end()) {
+        if (lit->keys.size() == 1) {
+            lit->bNoMore = true;
+            lit++;
+        } else if (lit->keys.empty())
+            lit = lNodes.erase(lit);
+        else
+            lit++;
+    }
+    bool bFinish = false;
+    typedef std::pair<int, Node*> SizeNode;
+    // decision D2: the reference compares (size, pointer); pointers are replaced by seq
+    auto less_d2 = [](const SizeNode& a, const SizeNode& b) {
+        if (a.first != b.first) return a.first < b.first;
+        return a.second->seq < b.second->seq;
+    };
+    std::vector<SizeNode> vSizeAndPointerToNode;
+    auto push_child = [&](Node& c, bool record, int* nToExpand) {
+        if (c.keys.size() > 0) {
+            c.seq = seq++;
+            lNodes.push_front(c);
+            if (c.keys.size() > 1) {
+                if (nToExpand) (*nToExpand)++;
+                if (record) vSizeAndPointerToNode.push_back(std::make_pair((int)c.keys.size(), &lNodes.front()));
+                lNodes.front().lit = lNodes.begin();
+            }
+        }
+    };
+    while (!bFinish) {
+        int prevSize = (int)lNodes.size();
+        lit = lNodes.begin();
+        int nToExpand = 0;
+        vSizeAndPointerToNode.clear();
+        while (lit != lNodes.end()) {
+            if (lit->bNoMore) {
+                lit++;
+                continue;
+            }
+            Node n1, n2, n3, n4;
+            divide_node(*lit, cands, n1, n2, n3, n4);
+            push_child(n1, true, &nToExpand);
+            push_child(n2, true, &nToExpand);
+            push_child(n3, true, &nToExpand);
+            push_child(n4, true, &nToExpand);
+            lit = lNodes.erase(lit);
+        }
+        if ((int)lNodes.size() >= N || (int)lNodes.size() == prevSize) {
+            bFinish = true;
+        } else if (((int)lNodes.size() + nToExpand * 3) > N) {
+            while (!bFinish) {
+                prevSize = (int)lNodes.size();
+                std::vector<SizeNode> vPrev = vSizeAndPointerToNode;
+                vSizeAndPointerToNode.clear();
+                std::sort(vPrev.begin(), vPrev.end(), less_d2);
+                for (int j = (int)vPrev.size() - 1; j >= 0; j--) {
+                    Node n1, n2, n3, n4;
+                    divide_node(*vPrev[j].second, cands, n1, n2, n3, n4);
+                    push_child(n1, true, nullptr);
+                    push_child(n2, true, nullptr);
+                    push_child(n3, true, nullptr);
+                    push_child(n4, true, nullptr);
+                    lNodes.erase(vPrev[j].second->lit);
+                    if ((int)lNodes.size() >= N) break;
+                }
+                if ((int)lNodes.size() >= N || (int)lNodes.size() == prevSize) bFinish = true;
+            }
+        }
+    }
+    int m = 0;
+    for (lit = lNodes.begin(); lit != lNodes.end(); lit++) {
+        const std::vector<int>& keys = lit->keys;
+        int best = keys[0];
+        float maxResponse = (float)cands[best].response;
+        for (size_t k = 1; k < keys.size(); k++) {
+            if ((float)cands[keys[k]].response > maxResponse) {
+                best = keys[k];
+                maxResponse = (float)cands[keys[k]].response;
+            }
+        }
+        if (m < cap) out_idx[m] = best;
+        m++;
+    }
+    return m;
+}
+
+// ---------------------------------------------------------------------------------------
+// cv::fastAtan2 scalar form, OpenCV 3.4.5 (call site :105).  Decision D3.
+extern "C" float orc_fast_atan2(float y, float x) {
+    static const float rad2deg = (float)(180 / 3.1415926535897932384626433832795);
+    static const float p1 = 0.9997878412794807f * rad2deg;
+    static const float p3 = -0.3258083974640975f * rad2deg;
+    static const float p5 = 0.1555786518463281f * rad2deg;
+    static const float p7 = -0.04432655554792128f * rad2deg;
+    static const float eps = (float)2.2204460492503131e-16;  // (float)DBL_EPSILON
+    float ax = std::fabs(x), ay = std::fabs(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + eps);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + eps);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// IC_Angle: :78-106.  (x, y) is the already rounded centre in level coordinates.
+extern "C" float orc_ic_angle(const uint8_t* img, int stride, int x, int y, const int* umax) {
+    int m_01 = 0, m_10 = 0;
+    const uint8_t* center = img + (size_t)y * stride + x;
+    for (int u = -HALF_PATCH_SIZE; u <= HALF_PATCH_SIZE; ++u) m_10 += u * center[u];
+    for (int v = 1; v <= HALF_PATCH_SIZE; ++v) {
+        int v_sum = 0;
+        int d = umax[v];
+        for (int u = -d; u <= d; ++u) {
+            int val_plus = center[u + v * stride], val_minus = center[u - v * stride];
+            v_sum += (val_plus - val_minus);
+            m_10 += u * (val_plus + val_minus);
+        }
+        m_01 += v * v_sum;
+    }
+    return orc_fast_atan2((float)m_01, (float)m_10);
+}
+
+// Decision D6: cos/sin of the float32 radian angle, evaluated in double with a fixed
+// operation sequence (so that any IEEE-754 machine reproduces it bit for bit) and rounded
+// once to float32.  Range reduction by multiples of pi/2 (two-term constant), then the
+// fdlibm __kernel_sin/__kernel_cos minimax polynomials on |r| <= pi/4.
+namespace {
+inline double ksin(double r) {
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double z = r * r;
+    double p = std::fma(z, S6, S5);
+    p = std::fma(z, p, S4);
+    p = std::fma(z, p, S3);
+    p = std::fma(z, p, S2);
+    p = std::fma(z, p, S1);
+    return std::fma(r * z, p, r);
+}
+inline double kcos(double r) {
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double z = r * r;
+    double p = std::fma(z, C6, C5);
+    p = std::fma(z, p, C4);
+    p = std::fma(z, p, C3);
+    p = std::fma(z, p, C2);
+    p = std::fma(z, p, C1);
+    double zz = z * z;
+    return std::fma(zz, p, std::fma(z, -0.5, 1.0));
+}
+void sincos_pinned(float angf, float* c_out, float* s_out) {
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double PIO2_HI = 1.57079632673412561417e+00;  // first 33 bits of pi/2
+    const double PIO2_LO = 6.07710050650619224932e-11;  // pi/2 - PIO2_HI
+    double x = (double)angf;
+    double kd = std::floor(std::fma(x, TWO_OVER_PI, 0.5));
+    double r = std::fma(-kd, PIO2_HI, x);
+    r = std::fma(-kd, PIO2_LO, r);
+    double s = ksin(r), c = kcos(r);
+    int k = (int)kd & 3;
+    double ss, cc;
+    switch (k) {
+        case 0: ss = s; cc = c; break;
+        case 1: ss = c; cc = -s; break;
+        case 2: ss = -s; cc = -c; break;
+        default: ss = -c; cc = s; break;
+    }
+    *c_out = (float)cc;
+    *s_out = (float)ss;
+}
+}  // namespace
+
+extern "C" void orc_sincos_deg(float angle_deg, float* cos_out, float* sin_out) {
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);  // :109
+    float angle = angle_deg * factorPI;                                          // :116
+    sincos_pinned(angle, cos_out, sin_out);
+}
+
+// computeOrbDescriptor: :112-152.  Decision D1 (FMA form) and D6 (a, b).
+extern "C" void orc_descriptor(const uint8_t* blurred, int stride, int x, int y, float angle_deg,
+                               uint8_t desc[32]) {
+    float a, b;
+    orc_sincos_deg(angle_deg, &a, &b);
+    const uint8_t* center = blurred + (size_t)y * stride + x;
+    const int8_t* pat = kPattern;
+    auto get = [&](int idx) -> int {
+        float px = (float)pat[2 * idx], py = (float)pat[2 * idx + 1];
+        int row = cv_roundf(std::fmaf(px, b, py * a));
+        int col = cv_roundf(std::fmaf(px, a, -(py * b)));
+        return center[row * stride + col];
+    };
+    for (int i = 0; i < 32; ++i, pat += 32) {
+        int val = 0;
+        for (int j = 0; j < 8; j++) {
+            int t0 = get(2 * j), t1 = get(2 * j + 1);
+            val |= (t0 < t1) << j;
+        }
+        desc[i] = (uint8_t)val;
+    }
+}
+
+extern "C" const int8_t* orc_pattern(void) { return kPattern; }
+
+// ---------------------------------------------------------------------------------------
+// Whole path: ORBextractor::operator() (:1137-1211), ComputePyramid (:1213-1250),
+// ComputeKeyPointsOctTree (:854-947).
+struct orc_ctx {
+    orc_params p;
+    int w[ORC_MAX_LEVELS], h[ORC_MAX_LEVELS];
+    std::vector<uint8_t> level[ORC_MAX_LEVELS], blurred[ORC_MAX_LEVELS];
+    std::vector<orc_cand> cands[ORC_MAX_LEVELS];
+    int nkp_level[ORC_MAX_LEVELS];
+    std::vector<orc_kp> kps;
+    std::vector<uint8_t> desc;
+};
+
+extern "C" orc_ctx* orc_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th) {
+    orc_ctx* c = new orc_ctx();
+    if (orc_params_init(&c->p, nfeatures, scale_factor, nlevels, ini_th, min_th) != 0) {
+        delete c;
+        return nullptr;
+    }
+    std::memset(c->w, 0, sizeof(c->w));
+    std::memset(c->h, 0, sizeof(c->h));
+    std::memset(c->nkp_level, 0, sizeof(c->nkp_level));
+    return c;
+}
+extern "C" void orc_destroy(orc_ctx* c) { delete c; }
+extern "C" const orc_params* orc_get_params(const orc_ctx* c) { return &c->p; }
+
+extern "C" int orc_extract(orc_ctx* c, const uint8_t* img, int w, int h, int stride) {
+    const orc_params& p = c->p;
+    c->kps.clear();
+    c->desc.clear();
+    if (!img || w <= 0 || h <= 0) return 0;  // :1140 (empty image: outputs untouched)
+    // ComputePyramid
+    for (int l = 0; l < p.nlevels; l++) {
+        orc_level_size(&p, w, h, l, &c->w[l], &c->h[l]);
+        if (c->w[l] < 1 || c->h[l] < 1) return -1;
+        c->level[l].resize((size_t)c->w[l] * c->h[l]);
+        if (l == 0) {
+            for (int y = 0; y < h; y++) std::memcpy(&c->level[0][(size_t)y * w], img + (size_t)y * stride, w);
+        } else {
+            orc_resize_linear(c->level[l - 1].data(), c->w[l - 1], c->h[l - 1], c->w[l - 1],
+                              c->level[l].data(), c->w[l], c->h[l], c->w[l]);
+        }
+    }
+    // ComputeKeyPointsOctTree
+    std::vector<std::vector<orc_kp>> all(p.nlevels);
+    for (int l = 0; l < p.nlevels; l++) {
+        const int lw = c->w[l], lh = c->h[l];
+        const int minBorderX = EDGE_THRESHOLD - 3, minBorderY = minBorderX;
+        const int maxBorderX = lw - EDGE_THRESHOLD + 3, maxBorderY = lh - EDGE_THRESHOLD + 3;
+        std::vector<orc_cand>& cd = c->cands[l];
+        cd.resize((size_t)((lw + 1) / 2) * ((lh + 1) / 2) + 16);
+        int n = orc_level_candidates(c->level[l].data(), lw, lh, lw, p.ini_th_fast, p.min_th_fast,
+                                     cd.data(), (int)cd.size());
+        if (n > (int)cd.size()) return -2;
+        cd.resize(n);
+        std::vector<int32_t> keep((size_t)n + 4);
+        int m = 0;
+        if (n > 0) {
+            m = orc_distribute_octree(cd.data(), n, minBorderX, maxBorderX, minBorderY, maxBorderY,
+                                      p.quota[l], keep.data(), (int)keep.size());
+            if (m < 0) return -3;
+        }
+        const int scaledPatchSize = (int)(PATCH_SIZE * p.scale[l]);  // :930
+        all[l].resize(m);
+        for (int i = 0; i < m; i++) {
+            const orc_cand& k = cd[keep[i]];
+            orc_kp& o = all[l][i];
+            o.x = (float)k.x + minBorderX;
+            o.y = (float)k.y + minBorderY;
+            o.size = (float)scaledPatchSize;
+            o.response = (float)k.response;
+            o.octave = l;
+            o.class_id = -1;
+            o.angle = -1.f;
+        }
+        c->nkp_level[l] = m;
+    }
+    for (int l = 0; l < p.nlevels; l++)
+        for (orc_kp& k : all[l])
+            k.angle = orc_ic_angle(c->level[l].data(), c->w[l], cv_roundf(k.x), cv_roundf(k.y), p.umax);
+    // descriptors, :1172-1210
+    int nkeypoints = 0;
+    for (int l = 0; l < p.nlevels; l++) nkeypoints += (int)all[l].size();
+    c->desc.resize((size_t)nkeypoints * 32);
+    c->kps.reserve(nkeypoints);
+    int offset = 0;
+    for (int l = 0; l < p.nlevels; l++) {
+        // the reference blurs only levels that hold keypoints; the blurred image of an empty
+        // level is never observable, so it is produced here unconditionally for the tests
+        c->blurred[l].resize((size_t)c->w[l] * c->h[l]);
+        orc_gaussian_blur7(c->level[l].data(), c->w[l], c->h[l], c->w[l], c->blurred[l].data(), c->w[l]);
+        std::vector<orc_kp>& kl = all[l];
+        if (kl.empty()) continue;
+        for (size_t i = 0; i < kl.size(); i++)
+            orc_descriptor(c->blurred[l].data(), c->w[l], cv_roundf(kl[i].x), cv_roundf(kl[i].y), kl[i].angle,
+                           &c->desc[(size_t)(offset + i) * 32]);
+        offset += (int)kl.size();
+        if (l != 0) {
+            float scale = p.scale[l];
+            for (orc_kp& k : kl) {
+                k.x *= scale;
+                k.y *= scale;
+            }
+        }
+        c->kps.insert(c->kps.end(), kl.begin(), kl.end());
+    }
+    return nkeypoints;
+}
+
+extern "C" int orc_num_keypoints(const orc_ctx* c) { return (int)c->kps.size(); }
+extern "C" void orc_get_keypoints(const orc_ctx* c, orc_kp* out) {
+    if (!c->kps.empty()) std::memcpy(out, c->kps.data(), c->kps.size() * sizeof(orc_kp));
+}
+extern "C" void orc_get_descriptors(const orc_ctx* c, uint8_t* out) {
+    if (!c->desc.empty()) std::memcpy(out, c->desc.data(), c->desc.size());
+}
+extern "C" void orc_get_level_dims(const orc_ctx* c, int level, int* w, int* h) {
+    *w = c->w[level];
+    *h = c->h[level];
+}
+extern "C" void orc_get_level(const orc_ctx* c, int level, uint8_t* out) {
+    std::memcpy(out, c->level[level].data(), c->level[level].size());
+}
+extern "C" void orc_get_blurred(const orc_ctx* c, int level, uint8_t* out) {
+    std::memcpy(out, c->blurred[level].data(), c->blurred[level].size());
+}
+extern "C" int orc_get_num_candidates(const orc_ctx* c, int level) { return (int)c->cands[level].size(); }
+extern "C" void orc_get_candidates(const orc_ctx* c, int level, orc_cand* out) {
+    if (!c->cands[level].empty())
+        std::memcpy(out, c->cands[level].data(), c->cands[level].size() * sizeof(orc_cand));
+}
+extern "C" int orc_get_num_level_keypoints(const orc_ctx* c, int level) { return c->nkp_level[level]; }
+
+// copyMakeBorder(..., 19,19,19,19, BORDER_REFLECT_101): :1239-1245
+extern "C" void orc_get_level_padded(const orc_ctx* c, int level, uint8_t* out) {
+    const int w = c->w[level], h = c->h[level], E = EDGE_THRESHOLD, pw = w + 2 * E;
+    const uint8_t* src = c->level[level].data();
+    for (int y = -E; y < h + E; y++) {
+        const uint8_t* S = src + (size_t)reflect101(y, h) * w;
+        uint8_t* D = out + (size_t)(y + E) * pw;
+        for (int x = -E; x < w + E; x++) D[x + E] = S[reflect101(x, w)];
+    }
+}

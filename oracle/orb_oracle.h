@@ -1,0 +1,110 @@
+/* CPU oracle for the ORB extractor hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A single-threaded, OpenCV-free restatement of ORB_SLAM2::ORBextractor
+ * (reference: src/ORBextractor.cc, include/ORBextractor.h) plus the five OpenCV 3.4.5
+ * primitives it calls (cv::resize INTER_LINEAR 8UC1, cv::FAST 9/16 with NMS,
+ * cv::GaussianBlur 7x7 sigma 2 on 8U, cv::fastAtan2, cvRound).
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this
+ * path, and OpenCV is not installed in the build environment, so the reference itself
+ * cannot be compiled or run.  The restatement is pinned only by hand-derivable
+ * known-answer tests (tests/test_oracle_kat.py) and by its own committed golden vectors.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and only as the checker / the CPU baseline -- never on the product path.
+ *
+ * Pinned decisions where the reference is not bit-deterministic:
+ *   D1  descriptor rotation uses the FMA-contracted form the reference's -march=native
+ *       build produces: col = rint(fmaf(x, a, -(y*b))), row = rint(fmaf(x, b, y*a)).
+ *   D2  quadtree node sort ties (pointer values in the reference) break on creation
+ *       sequence: among equal sizes the most recently created node is split first.
+ *   D3  fastAtan2 polynomial in IEEE float32, separate multiply and add.
+ *   D5  Gaussian taps 18,34,49,55,49,34,18 (sum 257, OpenCV 3.4.5 fixed-point path).
+ *   D6  a = cos, b = sin of the float32 radian angle are float32 roundings of a
+ *       double-precision evaluation (fixed range reduction + fdlibm kernels, explicit
+ *       fma) -- the correctly rounded value on every input checked.
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_LEVELS 16
+
+typedef struct orc_kp {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orc_kp; /* 28 bytes, field order of cv::KeyPoint */
+
+typedef struct orc_cand {
+    int32_t x, y;      /* relative to the level's (16,16) origin, as DistributeOctTree sees them */
+    int32_t response;  /* FAST score */
+} orc_cand;
+
+typedef struct orc_params {
+    int nfeatures;
+    float scale_factor;
+    int nlevels;
+    int ini_th_fast;
+    int min_th_fast;
+    /* derived (reference ctor, src/ORBextractor.cc:416-494) */
+    float scale[ORC_MAX_LEVELS], inv_scale[ORC_MAX_LEVELS];
+    float sigma2[ORC_MAX_LEVELS], inv_sigma2[ORC_MAX_LEVELS];
+    int quota[ORC_MAX_LEVELS];
+    int umax[16];
+} orc_params;
+
+typedef struct orc_ctx orc_ctx; /* holds every intermediate of the last extraction */
+
+/* constructor arithmetic; returns 0 or a negative error */
+int orc_params_init(orc_params* p, int nfeatures, float scale_factor, int nlevels,
+                    int ini_th, int min_th);
+void orc_level_size(const orc_params* p, int w0, int h0, int level, int* w, int* h);
+
+/* primitives */
+void orc_resize_linear(const uint8_t* src, int sw, int sh, int sstride,
+                       uint8_t* dst, int dw, int dh, int dstride);
+void orc_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
+/* cv::FAST(img, kps, threshold, nonmax=true); returns count, writes up to cap (x,y,score) */
+int orc_fast(const uint8_t* img, int w, int h, int stride, int threshold,
+             orc_cand* out, int cap);
+/* per-level candidate list in (cell row, cell col, y, x) order; returns count */
+int orc_level_candidates(const uint8_t* img, int w, int h, int stride, int ini_th, int min_th,
+                         orc_cand* out, int cap);
+/* DistributeOctTree: writes indices (into cands) of retained points in list order */
+int orc_distribute_octree(const orc_cand* cands, int n, int minX, int maxX, int minY, int maxY,
+                          int N, int32_t* out_idx, int cap);
+float orc_fast_atan2(float y, float x);
+float orc_ic_angle(const uint8_t* img, int stride, int x, int y, const int* umax);
+void orc_sincos_deg(float angle_deg, float* cos_out, float* sin_out);
+void orc_descriptor(const uint8_t* blurred, int stride, int x, int y, float angle_deg,
+                    uint8_t desc[32]);
+const int8_t* orc_pattern(void); /* 1024 values */
+
+/* whole path */
+orc_ctx* orc_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th);
+void orc_destroy(orc_ctx* c);
+const orc_params* orc_get_params(const orc_ctx* c);
+/* returns number of keypoints, or negative error */
+int orc_extract(orc_ctx* c, const uint8_t* img, int w, int h, int stride);
+int orc_num_keypoints(const orc_ctx* c);
+void orc_get_keypoints(const orc_ctx* c, orc_kp* out);
+void orc_get_descriptors(const orc_ctx* c, uint8_t* out);
+/* intermediates of the last orc_extract */
+void orc_get_level_dims(const orc_ctx* c, int level, int* w, int* h);
+void orc_get_level(const orc_ctx* c, int level, uint8_t* out);          /* w*h, un-blurred */
+void orc_get_blurred(const orc_ctx* c, int level, uint8_t* out);        /* w*h */
+int orc_get_num_candidates(const orc_ctx* c, int level);
+void orc_get_candidates(const orc_ctx* c, int level, orc_cand* out);
+int orc_get_num_level_keypoints(const orc_ctx* c, int level);
+/* 19-pixel reflect-101 padded level as ComputePyramid builds it: (w+38)*(h+38) */
+void orc_get_level_padded(const orc_ctx* c, int level, uint8_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

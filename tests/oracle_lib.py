@@ -1,0 +1,234 @@
+"""ctypes view of oracle/liborb_oracle.so (the CPU restatement; test infrastructure only).
+
+Imported by tests/, by __graft_entry__.smoke() and by bench.py's cpu_baseline leg; never by
+the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB_PATH = os.path.join(_ROOT, "oracle", "liborb_oracle.so")
+
+MAX_LEVELS = 16
+
+
+class OrcKp(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("size", C.c_float), ("angle", C.c_float),
+                ("response", C.c_float), ("octave", C.c_int32), ("class_id", C.c_int32)]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+CAND_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("response", "<i4")])
+
+
+class OrcParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
+                ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int),
+                ("scale", C.c_float * MAX_LEVELS), ("inv_scale", C.c_float * MAX_LEVELS),
+                ("sigma2", C.c_float * MAX_LEVELS), ("inv_sigma2", C.c_float * MAX_LEVELS),
+                ("quota", C.c_int * MAX_LEVELS), ("umax", C.c_int * 16)]
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_ROOT, "oracle", "orb_oracle.cpp")):
+        subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        u8p = C.POINTER(C.c_uint8)
+        L.orc_params_init.argtypes = [C.POINTER(OrcParams), C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orc_level_size.argtypes = [C.POINTER(OrcParams), C.c_int, C.c_int, C.c_int,
+                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_resize_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_gaussian_blur7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_fast.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_level_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_int]
+        L.orc_distribute_octree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_int]
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_ic_angle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.orc_ic_angle.restype = C.c_float
+        L.orc_sincos_deg.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_descriptor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        L.orc_pattern.restype = C.POINTER(C.c_int8)
+        L.orc_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orc_create.restype = C.c_void_p
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_get_params.argtypes = [C.c_void_p]
+        L.orc_get_params.restype = C.POINTER(OrcParams)
+        L.orc_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_num_keypoints.argtypes = [C.c_void_p]
+        L.orc_get_keypoints.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_get_descriptors.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_get_level_dims.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_get_level.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_get_blurred.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_get_num_candidates.argtypes = [C.c_void_p, C.c_int]
+        L.orc_get_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_get_num_level_keypoints.argtypes = [C.c_void_p, C.c_int]
+        L.orc_get_level_padded.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        _ = u8p
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def params(nfeatures, scale_factor, nlevels, ini_th=20, min_th=7):
+    p = OrcParams()
+    rc = lib().orc_params_init(C.byref(p), nfeatures, scale_factor, nlevels, ini_th, min_th)
+    assert rc == 0
+    return p
+
+
+def level_size(p, w0, h0, level):
+    w, h = C.c_int(), C.c_int()
+    lib().orc_level_size(C.byref(p), w0, h0, level, C.byref(w), C.byref(h))
+    return w.value, h.value
+
+
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    dst = np.empty((dh, dw), dtype=np.uint8)
+    lib().orc_resize_linear(_ptr(src), src.shape[1], src.shape[0], src.shape[1], _ptr(dst), dw, dh, dw)
+    return dst
+
+
+def gaussian_blur7(src):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    dst = np.empty_like(src)
+    lib().orc_gaussian_blur7(_ptr(src), src.shape[1], src.shape[0], src.shape[1], _ptr(dst), src.shape[1])
+    return dst
+
+
+def fast(img, threshold):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    cap = img.size
+    out = np.zeros(cap, dtype=CAND_DTYPE)
+    n = lib().orc_fast(_ptr(img), img.shape[1], img.shape[0], img.shape[1], threshold, _ptr(out), cap)
+    return out[:n]
+
+
+def level_candidates(img, ini_th=20, min_th=7):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    cap = img.size
+    out = np.zeros(cap, dtype=CAND_DTYPE)
+    n = lib().orc_level_candidates(_ptr(img), img.shape[1], img.shape[0], img.shape[1], ini_th, min_th,
+                                   _ptr(out), cap)
+    return out[:n]
+
+
+def distribute_octree(cands, minX, maxX, minY, maxY, N):
+    cands = np.ascontiguousarray(cands, dtype=CAND_DTYPE)
+    cap = len(cands) + 8
+    out = np.zeros(cap, dtype=np.int32)
+    m = lib().orc_distribute_octree(_ptr(cands), len(cands), minX, maxX, minY, maxY, N, _ptr(out), cap)
+    assert m >= 0, m
+    return out[:m]
+
+
+def fast_atan2(y, x):
+    return float(lib().orc_fast_atan2(float(y), float(x)))
+
+
+def ic_angle(img, x, y, umax):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    um = (C.c_int * 16)(*umax)
+    return float(lib().orc_ic_angle(_ptr(img), img.shape[1], x, y, um))
+
+
+def sincos_deg(angle):
+    c, s = C.c_float(), C.c_float()
+    lib().orc_sincos_deg(float(angle), C.byref(c), C.byref(s))
+    return c.value, s.value
+
+
+def descriptor(blurred, x, y, angle):
+    blurred = np.ascontiguousarray(blurred, dtype=np.uint8)
+    d = np.zeros(32, dtype=np.uint8)
+    lib().orc_descriptor(_ptr(blurred), blurred.shape[1], x, y, float(angle), _ptr(d))
+    return d
+
+
+def pattern():
+    p = lib().orc_pattern()
+    return np.ctypeslib.as_array(p, shape=(1024,)).copy()
+
+
+class Oracle:
+    """Whole-path CPU extractor with access to every intermediate."""
+
+    def __init__(self, nfeatures, scale_factor, nlevels, ini_th=20, min_th=7):
+        self._c = lib().orc_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        assert self._c
+        self.nlevels = nlevels
+
+    def __del__(self):
+        if getattr(self, "_c", None):
+            lib().orc_destroy(self._c)
+            self._c = None
+
+    @property
+    def params(self):
+        return lib().orc_get_params(self._c).contents
+
+    def extract(self, img):
+        img = np.asarray(img)
+        assert img.dtype == np.uint8 and img.ndim == 2 and img.strides[1] == 1
+        n = lib().orc_extract(self._c, _ptr(img), img.shape[1], img.shape[0], img.strides[0])
+        assert n >= 0, n
+        kps = np.zeros(n, dtype=KP_DTYPE)
+        desc = np.zeros((n, 32), dtype=np.uint8)
+        lib().orc_get_keypoints(self._c, _ptr(kps))
+        lib().orc_get_descriptors(self._c, _ptr(desc))
+        return kps, desc
+
+    def level_dims(self, l):
+        w, h = C.c_int(), C.c_int()
+        lib().orc_get_level_dims(self._c, l, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def level(self, l):
+        w, h = self.level_dims(l)
+        a = np.empty((h, w), dtype=np.uint8)
+        lib().orc_get_level(self._c, l, _ptr(a))
+        return a
+
+    def blurred(self, l):
+        w, h = self.level_dims(l)
+        a = np.empty((h, w), dtype=np.uint8)
+        lib().orc_get_blurred(self._c, l, _ptr(a))
+        return a
+
+    def padded_level(self, l):
+        w, h = self.level_dims(l)
+        a = np.empty((h + 38, w + 38), dtype=np.uint8)
+        lib().orc_get_level_padded(self._c, l, _ptr(a))
+        return a
+
+    def candidates(self, l):
+        n = lib().orc_get_num_candidates(self._c, l)
+        a = np.zeros(n, dtype=CAND_DTYPE)
+        lib().orc_get_candidates(self._c, l, _ptr(a))
+        return a
+
+    def level_keypoint_count(self, l):
+        return lib().orc_get_num_level_keypoints(self._c, l)
