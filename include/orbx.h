@@ -1,0 +1,164 @@
+/* orbx -- C ABI of the MI355X (gfx950) ORB feature extractor.
+ *
+ * This is the boundary a host program binds to replace ORB_SLAM2::ORBextractor
+ * (reference include/ORBextractor.h:45-111, src/ORBextractor.cc).  Plain pointers and sizes
+ * only; no C++ or torch types.  All functions return 0 (ORBX_OK) or a negative error code
+ * and never throw.  Outputs are allocated by the caller.
+ *
+ * A context owns one HIP stream and all device scratch; contexts are independent and may
+ * be used from different host threads at the same time (the reference runs two extractor
+ * instances on two threads for stereo, src/Frame.cc:78-81).  One context is not re-entrant.
+ */
+#ifndef ORBX_H
+#define ORBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBX_MAX_LEVELS 16
+
+enum {
+    ORBX_OK = 0,
+    ORBX_E_INVALID = -1,   /* bad argument */
+    ORBX_E_HIP = -2,       /* a HIP runtime call failed (see orbx_last_hip_error) */
+    ORBX_E_NO_DEVICE = -3, /* no usable GPU */
+    ORBX_E_CAPACITY = -4,  /* image/batch larger than the context was created for, or kp_cap too small */
+    ORBX_E_GEOMETRY = -5,  /* pyramid level too small for the 30-px cell grid, or too wide */
+    ORBX_E_STATE = -6      /* no extraction has run yet (pyramid read-back) */
+};
+
+/* Same field order and size (28 bytes) as cv::KeyPoint. */
+typedef struct orbx_kp {
+    float x, y;      /* level-0 pixel coordinates (level coords * scale factor of the octave) */
+    float size;      /* float(int(31 * scale)) */
+    float angle;     /* degrees, [0, 360) */
+    float response;  /* FAST score */
+    int32_t octave;
+    int32_t class_id; /* -1 */
+} orbx_kp;
+
+/* Replaces the constructor arguments of ORBextractor::ORBextractor
+ * (reference include/ORBextractor.h:51-52, src/ORBextractor.cc:416-423) plus sizing. */
+typedef struct orbx_params {
+    int32_t nfeatures;
+    float scale_factor;
+    int32_t nlevels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+    int32_t device_id;   /* HIP device ordinal */
+    int32_t max_width;   /* largest image the context must accept */
+    int32_t max_height;
+    int32_t max_batch;   /* largest number of frames per call */
+    uint32_t flags;      /* reserved, 0 */
+} orbx_params;
+
+typedef struct orbx_level_geom {
+    int32_t width, height;     /* level image size (reference src/ORBextractor.cc:1220-1221) */
+    int32_t n_cols, n_rows;    /* FAST cell grid (:871-877) */
+    int32_t w_cell, h_cell;
+    int32_t n_cells;           /* cells actually visited (:885-895 skip rules applied) */
+    int32_t n_ini;             /* quadtree roots (:576) */
+    int32_t quota;             /* mnFeaturesPerLevel[level] (:447-463) */
+} orbx_level_geom;
+
+typedef struct orbx_ctx orbx_ctx;
+
+/* ---- host-only helpers (no GPU needed) ------------------------------------------------ */
+
+/* Constructor tables: mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2,
+ * mnFeaturesPerLevel (each nlevels long) and umax (16).  Replaces what the getters
+ * GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares return (reference include/ORBextractor.h:69-83).
+ * Any output pointer may be NULL. */
+int orbx_host_tables(int nfeatures, float scale_factor, int nlevels,
+                     float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                     int32_t* quota, int32_t* umax16);
+
+/* Per-level geometry for a w x h input (reference src/ORBextractor.cc:862-897, 576, 1220). */
+int orbx_host_level_geometry(int nfeatures, float scale_factor, int nlevels,
+                             int width, int height, int level, orbx_level_geom* out);
+
+/* Fixed-point bilinear taps for one axis (cv::resize INTER_LINEAR 8UC1, call site
+ * src/ORBextractor.cc:1237): for each of dn destination indices the source index and the two
+ * 11-bit coefficients.  clamp_index != 0 applies the horizontal rule (index clamped, weight
+ * zeroed); 0 applies the vertical rule (index left unclamped, may be -1 or sn-1). */
+int orbx_host_resize_taps(int sn, int dn, int clamp_index, int32_t* ofs, int16_t* c0, int16_t* c1);
+
+/* Upper bound on keypoints returned per image for these parameters and image size. */
+int orbx_host_max_keypoints(int nfeatures, float scale_factor, int nlevels, int width, int height);
+
+/* ---- context -------------------------------------------------------------------------- */
+
+/* Replaces `new ORBextractor(...)` (reference src/Tracking.cc:121,125,128). */
+int orbx_create(const orbx_params* params, orbx_ctx** out);
+/* Releases stream and device memory (the reference destructor is trivial,
+ * include/ORBextractor.h:54). */
+void orbx_destroy(orbx_ctx* ctx);
+
+/* ---- extraction ----------------------------------------------------------------------- */
+
+/* One 8-bit gray image in host memory.  Replaces ORBextractor::operator()
+ * (reference include/ORBextractor.h:59-61, src/ORBextractor.cc:1137-1211); the mask argument
+ * of the reference is ignored there and has no counterpart here.
+ * kps[kp_cap], desc[kp_cap*32]; *n_out receives the keypoint count.
+ * kp_cap must be >= orbx_host_max_keypoints(...) for this image size. */
+int orbx_extract(orbx_ctx* ctx, const uint8_t* img, int width, int height, int stride,
+                 orbx_kp* kps, int kp_cap, uint8_t* desc, int* n_out);
+
+/* n images of one size in host memory; image i starts at imgs[i] with row stride strides[i].
+ * kps[n*kp_cap], desc[n*kp_cap*32], n_out[n].  The throughput entry point: the reference
+ * processes one image per call (src/Frame.cc:249-255); batching has no counterpart there. */
+int orbx_extract_batch(orbx_ctx* ctx, int n, const uint8_t* const* imgs, int width, int height,
+                       const int* strides, orbx_kp* kps, int kp_cap, uint8_t* desc, int* n_out);
+
+/* As orbx_extract_batch with every buffer already in device memory (HBM-resident input,
+ * HBM-resident results).  d_imgs holds n images, image i at d_imgs + i*frame_stride, rows
+ * `stride` bytes apart.  d_kps[n*kp_cap], d_desc[n*kp_cap*32], d_n_out[n] are device
+ * pointers.  Work is enqueued on the context's stream; if `sync` is non-zero the call
+ * returns after the stream has drained, otherwise use orbx_synchronize. */
+int orbx_extract_batch_device(orbx_ctx* ctx, int n, const uint8_t* d_imgs, int width, int height,
+                              int stride, size_t frame_stride, orbx_kp* d_kps, int kp_cap,
+                              uint8_t* d_desc, int32_t* d_n_out, int sync);
+
+int orbx_synchronize(orbx_ctx* ctx);
+
+/* Copies pyramid level `level` of image `img_idx` of the LAST extraction to host memory
+ * (un-padded, rows dst_stride apart).  Replaces reads of the public member mvImagePyramid
+ * (reference include/ORBextractor.h:85; read by src/Frame.cc:492,582,594,599). */
+int orbx_pyramid_level(orbx_ctx* ctx, int img_idx, int level, uint8_t* dst, int dst_stride,
+                       int* width, int* height);
+
+/* ---- introspection for tests and measurement ------------------------------------------- */
+
+enum {
+    ORBX_DBG_BLURRED = 1,     /* level image after the 7x7 Gaussian, w*h bytes               */
+    ORBX_DBG_CANDIDATES = 2,  /* int32 triplets (x, y, response), (cell row, cell col, y, x)  */
+    ORBX_DBG_LEVEL_KPS = 3    /* int32 triplets (x, y, response) of retained points, level
+                                 coordinates, quadtree list order                             */
+};
+/* Reads an intermediate of the last extraction into dst (capacity cap_bytes); *n_bytes
+ * receives the size.  No counterpart in the reference (its intermediates are locals). */
+int orbx_debug_read(orbx_ctx* ctx, int what, int img_idx, int level, void* dst, size_t cap_bytes,
+                    size_t* n_bytes);
+
+/* Stage timing with HIP events on the context's stream.  Stages, in order:
+ * 0 pyramid, 1 fast, 2 quadtree, 3 blur, 4 orient+describe. */
+#define ORBX_NUM_STAGES 5
+int orbx_set_profiling(orbx_ctx* ctx, int enable);
+/* Milliseconds per stage of the last extraction (valid after it has been synchronised). */
+int orbx_get_stage_ms(orbx_ctx* ctx, float ms[ORBX_NUM_STAGES]);
+const char* orbx_stage_name(int stage);
+
+const char* orbx_strerror(int code);
+/* hipError_t of the last failed HIP call on this context (0 if none). */
+int orbx_last_hip_error(const orbx_ctx* ctx);
+const char* orbx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBX_H */

@@ -1,0 +1,293 @@
+"""orb_slam2_amd -- MI355X-native ORB feature extraction behind the ORB_SLAM2::ORBextractor API.
+
+The product is `liborbx.so` (hand-written HIP for gfx950 behind the C ABI of include/orbx.h).
+This package is the Python host-side mirror of the reference class
+(reference include/ORBextractor.h:45-111): same constructor arguments, call operator, getters
+and the `mvImagePyramid` member.  There is no CPU fallback: without the library, or without a
+GPU, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborbx.so")
+
+MAX_LEVELS = 16
+NUM_STAGES = 5
+EDGE_THRESHOLD = 19
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+DBG_BLURRED, DBG_CANDIDATES, DBG_LEVEL_KPS = 1, 2, 3
+
+
+class OrbxError(RuntimeError):
+    pass
+
+
+class _Params(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("device_id", C.c_int32),
+                ("max_width", C.c_int32), ("max_height", C.c_int32), ("max_batch", C.c_int32),
+                ("flags", C.c_uint32)]
+
+
+class LevelGeom(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("n_cols", C.c_int32), ("n_rows", C.c_int32),
+                ("w_cell", C.c_int32), ("h_cell", C.c_int32), ("n_cells", C.c_int32), ("n_ini", C.c_int32),
+                ("quota", C.c_int32)]
+
+
+EXPORTS = [
+    "orbx_host_tables", "orbx_host_level_geometry", "orbx_host_resize_taps", "orbx_host_max_keypoints",
+    "orbx_create", "orbx_destroy", "orbx_extract", "orbx_extract_batch", "orbx_extract_batch_device",
+    "orbx_synchronize", "orbx_pyramid_level", "orbx_debug_read", "orbx_set_profiling", "orbx_get_stage_ms",
+    "orbx_stage_name", "orbx_strerror", "orbx_last_hip_error", "orbx_version",
+]
+
+_lib = None
+
+
+def load_library():
+    """Load liborbx.so (raises OrbxError if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OrbxError("liborbx.so not built: run `make -C orb_slam2_amd/csrc` (or __graft_entry__.build())")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
+    L.orbx_host_tables.argtypes = [i32, f32, i32, vp, vp, vp, vp, vp, vp]
+    L.orbx_host_level_geometry.argtypes = [i32, f32, i32, i32, i32, i32, C.POINTER(LevelGeom)]
+    L.orbx_host_resize_taps.argtypes = [i32, i32, i32, vp, vp, vp]
+    L.orbx_host_max_keypoints.argtypes = [i32, f32, i32, i32, i32]
+    L.orbx_create.argtypes = [C.POINTER(_Params), C.POINTER(vp)]
+    L.orbx_destroy.argtypes = [vp]
+    L.orbx_destroy.restype = None
+    L.orbx_extract.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, C.POINTER(i32)]
+    L.orbx_extract_batch.argtypes = [vp, i32, vp, i32, i32, vp, vp, i32, vp, vp]
+    L.orbx_extract_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, vp, i32, vp, vp, i32]
+    L.orbx_synchronize.argtypes = [vp]
+    L.orbx_pyramid_level.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.orbx_debug_read.argtypes = [vp, i32, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.orbx_set_profiling.argtypes = [vp, i32]
+    L.orbx_get_stage_ms.argtypes = [vp, vp]
+    L.orbx_stage_name.argtypes = [i32]
+    L.orbx_stage_name.restype = C.c_char_p
+    L.orbx_strerror.argtypes = [i32]
+    L.orbx_strerror.restype = C.c_char_p
+    L.orbx_last_hip_error.argtypes = [vp]
+    L.orbx_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def _check(rc, ctx=None):
+    if rc != 0:
+        L = load_library()
+        msg = L.orbx_strerror(rc).decode()
+        if ctx is not None and rc == -2:
+            msg += " (hipError %d)" % L.orbx_last_hip_error(ctx)
+        raise OrbxError("orbx: %s (%d)" % (msg, rc))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def host_tables(nfeatures, scale_factor, nlevels):
+    """Constructor tables of the reference (no GPU needed)."""
+    L = load_library()
+    f = [np.zeros(nlevels, np.float32) for _ in range(4)]
+    quota = np.zeros(nlevels, np.int32)
+    umax = np.zeros(16, np.int32)
+    _check(L.orbx_host_tables(nfeatures, scale_factor, nlevels, _ptr(f[0]), _ptr(f[1]), _ptr(f[2]), _ptr(f[3]),
+                              _ptr(quota), _ptr(umax)))
+    return {"scale": f[0], "inv_scale": f[1], "sigma2": f[2], "inv_sigma2": f[3], "quota": quota, "umax": umax}
+
+
+def host_level_geometry(nfeatures, scale_factor, nlevels, width, height, level):
+    g = LevelGeom()
+    _check(load_library().orbx_host_level_geometry(nfeatures, scale_factor, nlevels, width, height, level, C.byref(g)))
+    return g
+
+
+def host_resize_taps(sn, dn, clamp_index):
+    ofs = np.zeros(dn, np.int32)
+    c0 = np.zeros(dn, np.int16)
+    c1 = np.zeros(dn, np.int16)
+    _check(load_library().orbx_host_resize_taps(sn, dn, int(clamp_index), _ptr(ofs), _ptr(c0), _ptr(c1)))
+    return ofs, c0, c1
+
+
+def host_max_keypoints(nfeatures, scale_factor, nlevels, width, height):
+    rc = load_library().orbx_host_max_keypoints(nfeatures, scale_factor, nlevels, width, height)
+    if rc < 0:
+        _check(rc)
+    return rc
+
+
+class ORBextractor:
+    """Mirror of ORB_SLAM2::ORBextractor on the MI355X.
+
+    ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) as in the reference
+    (include/ORBextractor.h:51-52); the keyword arguments size the device context.
+    """
+
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, *, device=0,
+                 max_width=1280, max_height=1024, max_batch=1, keep_pyramid=True):
+        self._ctx = None
+        L = load_library()
+        self._L = L
+        self.nfeatures, self.nlevels = int(nfeatures), int(nlevels)
+        self.scaleFactor = float(np.float32(scaleFactor))
+        self.iniThFAST, self.minThFAST = int(iniThFAST), int(minThFAST)
+        t = host_tables(self.nfeatures, self.scaleFactor, self.nlevels)
+        self.mvScaleFactor, self.mvInvScaleFactor = t["scale"], t["inv_scale"]
+        self.mvLevelSigma2, self.mvInvLevelSigma2 = t["sigma2"], t["inv_sigma2"]
+        self.mnFeaturesPerLevel, self.umax = t["quota"], t["umax"]
+        self.mvImagePyramid = [None] * self.nlevels
+        self.keep_pyramid = keep_pyramid
+        p = _Params(self.nfeatures, self.scaleFactor, self.nlevels, self.iniThFAST, self.minThFAST, device,
+                    max_width, max_height, max_batch, 0)
+        ctx = C.c_void_p()
+        _check(L.orbx_create(C.byref(p), C.byref(ctx)))
+        self._ctx = ctx
+        self._max = (max_width, max_height, max_batch)
+        self._size = (max_width, max_height)
+
+    def close(self):
+        if self._ctx is not None:
+            self._L.orbx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- getters of the reference (include/ORBextractor.h:63-83) ----
+    def GetLevels(self):
+        return self.nlevels
+
+    def GetScaleFactor(self):
+        return self.scaleFactor
+
+    def GetScaleFactors(self):
+        return self.mvScaleFactor.copy()
+
+    def GetInverseScaleFactors(self):
+        return self.mvInvScaleFactor.copy()
+
+    def GetScaleSigmaSquares(self):
+        return self.mvLevelSigma2.copy()
+
+    def GetInverseScaleSigmaSquares(self):
+        return self.mvInvLevelSigma2.copy()
+
+    def max_keypoints(self, width, height):
+        return host_max_keypoints(self.nfeatures, self.scaleFactor, self.nlevels, width, height)
+
+    # ---- operator() of the reference (include/ORBextractor.h:59-61) ----
+    def __call__(self, image, mask=None):
+        """Returns (keypoints[K] structured array, descriptors[K,32] uint8).
+
+        An empty image returns (None, None) -- the reference returns without touching its
+        outputs (src/ORBextractor.cc:1140-1141).  `mask` is ignored, as in the reference.
+        With no keypoints the descriptor array is empty (reference releases it, :1160-1161).
+        """
+        if image is None or getattr(image, "size", 0) == 0:
+            return None, None
+        image = np.asarray(image)
+        if image.dtype != np.uint8 or image.ndim != 2:
+            raise OrbxError("image must be 8-bit single channel (CV_8UC1)")  # reference asserts, :1144
+        if image.strides[1] != 1:
+            image = np.ascontiguousarray(image)
+        h, w = image.shape
+        self._size = (w, h)
+        cap = self.max_keypoints(w, h)
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        _check(self._L.orbx_extract(self._ctx, _ptr(image), w, h, image.strides[0], _ptr(kps), cap, _ptr(desc),
+                                    C.byref(n)), self._ctx)
+        if self.keep_pyramid:
+            self.mvImagePyramid = [self.pyramid_level(0, l, padded=True) for l in range(self.nlevels)]
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch(self, images):
+        """images: (n, h, w) uint8 array or list of equally sized 2-D arrays, host memory."""
+        imgs = [np.asarray(im) for im in images]
+        n = len(imgs)
+        h, w = imgs[0].shape
+        for k, im in enumerate(imgs):
+            if im.dtype != np.uint8 or im.shape != (h, w):
+                raise OrbxError("batch images must be uint8 and equally sized")
+            if im.strides[1] != 1:
+                imgs[k] = np.ascontiguousarray(im)
+        self._size = (w, h)
+        cap = self.max_keypoints(w, h)
+        ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        strides = np.array([im.strides[0] for im in imgs], np.int32)
+        kps = np.zeros((n, cap), KP_DTYPE)
+        desc = np.zeros((n, cap, 32), np.uint8)
+        cnt = np.zeros(n, np.int32)
+        _check(self._L.orbx_extract_batch(self._ctx, n, ptrs, w, h, _ptr(strides), _ptr(kps), cap, _ptr(desc),
+                                          _ptr(cnt)), self._ctx)
+        return [(kps[i, :cnt[i]].copy(), desc[i, :cnt[i]].copy()) for i in range(n)]
+
+    def extract_batch_device(self, d_imgs, n, width, height, stride, frame_stride, d_kps, kp_cap, d_desc, d_n,
+                             sync=True):
+        """All arguments are raw device addresses (ints); see orbx_extract_batch_device."""
+        self._size = (width, height)
+        _check(self._L.orbx_extract_batch_device(self._ctx, n, C.c_void_p(d_imgs), width, height, stride,
+                                                 frame_stride, C.c_void_p(d_kps), kp_cap, C.c_void_p(d_desc),
+                                                 C.c_void_p(d_n), int(sync)), self._ctx)
+
+    def synchronize(self):
+        _check(self._L.orbx_synchronize(self._ctx), self._ctx)
+
+    # ---- pyramid read-back: the public member mvImagePyramid (include/ORBextractor.h:85) ----
+    def pyramid_level(self, img_idx, level, padded=False):
+        """Level image of the last extraction.  padded=True returns the view the reference
+        keeps: the level inside a buffer with a 19-px reflect-101 border
+        (src/ORBextractor.cc:1227-1245); the returned array is the un-padded ROI of it."""
+        g = host_level_geometry(self.nfeatures, self.scaleFactor, self.nlevels, *self._last_size(), level)
+        w, h = g.width, g.height
+        E = EDGE_THRESHOLD
+        if padded:
+            buf = np.empty((h + 2 * E, w + 2 * E), np.uint8)
+            roi = buf[E:E + h, E:E + w]
+        else:
+            buf = roi = np.empty((h, w), np.uint8)
+        ww, hh = C.c_int(), C.c_int()
+        _check(self._L.orbx_pyramid_level(self._ctx, img_idx, level, roi.ctypes.data_as(C.c_void_p), roi.strides[0],
+                                          C.byref(ww), C.byref(hh)), self._ctx)
+        assert (ww.value, hh.value) == (w, h)
+        if padded:
+            buf[:] = np.pad(roi, E, mode="reflect")
+            return buf[E:E + h, E:E + w]
+        return roi
+
+    def _last_size(self):
+        return self._size
+
+    # ---- test / measurement hooks ----
+    def debug_read(self, what, img_idx, level, max_bytes=1 << 26):
+        buf = np.zeros(max_bytes, np.uint8)
+        n = C.c_size_t(0)
+        _check(self._L.orbx_debug_read(self._ctx, what, img_idx, level, _ptr(buf), max_bytes, C.byref(n)), self._ctx)
+        return buf[:n.value].copy()
+
+    def set_profiling(self, on):
+        _check(self._L.orbx_set_profiling(self._ctx, int(on)), self._ctx)
+
+    def stage_ms(self):
+        ms = np.zeros(NUM_STAGES, np.float32)
+        _check(self._L.orbx_get_stage_ms(self._ctx, _ptr(ms)), self._ctx)
+        return {self._L.orbx_stage_name(i).decode(): float(ms[i]) for i in range(NUM_STAGES)}

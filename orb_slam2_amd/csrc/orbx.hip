@@ -1,0 +1,523 @@
+// C ABI of the gfx950 ORB extractor: context, device memory, launch sequence.
+// Declared in include/orbx.h.  Compiled with: hipcc --offload-arch=gfx950 -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "kernels_describe.hpp"
+#include "kernels_fast.hpp"
+#include "kernels_octree.hpp"
+#include "kernels_pyramid.hpp"
+#include "orbx_device.h"
+#include "orbx_host.h"
+
+using namespace orbx;
+
+namespace {
+
+const int8_t kPattern[1024] = {
+#include "../../include/orb_pattern_31.inc"
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct orbx_ctx {
+    orbx_params prm;
+    Tables tab;
+    hipStream_t stream = nullptr;
+    int last_hip = 0;
+
+    // geometry of the current image size
+    int cur_w = -1, cur_h = -1;
+    std::vector<LevelGeom> levels;
+    std::vector<CellDesc> cells;
+    int pitch[ORBX_MAX_LEVELS];
+    size_t plane[ORBX_MAX_LEVELS];
+    int cell_cap = 0, total_cells = 0, dense_total = 0, kp_total = 0, max_kp_level = 0;
+    size_t oct_lds = 0;
+
+    // device tables
+    DevBuf d_cells, d_ic, d_pat;
+    DevBuf d_xt[ORBX_MAX_LEVELS], d_yt[ORBX_MAX_LEVELS];
+    // device arenas (grown on demand)
+    DevBuf d_pyr, d_blur, d_cand, d_ccount, d_dense_pts, d_dense_node, d_lvl_kps, d_lvl_count;
+    DevBuf d_out_kps, d_out_desc, d_out_n;  // results of the host-memory entry points
+
+    // last batch (for read-backs)
+    BatchDev B;
+    bool have_last = false;
+
+    bool profiling = false;
+    hipEvent_t ev[ORBX_NUM_STAGES + 1];
+    bool ev_made = false;
+    bool ev_valid = false;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                        \
+    do {                                          \
+        hipError_t e_ = (expr);                   \
+        if (e_ != hipSuccess) {                   \
+            (ctx)->last_hip = (int)e_;            \
+            return ORBX_E_HIP;                    \
+        }                                         \
+    } while (0)
+
+int ensure(orbx_ctx* c, DevBuf* b, size_t bytes) {
+    if (bytes <= b->bytes) return ORBX_OK;
+    if (b->p) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipFree(b->p));
+        b->p = nullptr;
+        b->bytes = 0;
+    }
+    bytes = align_up(bytes + 256, 4096);
+    HIP_TRY(c, hipMalloc(&b->p, bytes));
+    b->bytes = bytes;
+    return ORBX_OK;
+}
+
+void release(DevBuf* b) {
+    if (b->p) (void)hipFree(b->p);
+    b->p = nullptr;
+    b->bytes = 0;
+}
+
+// Rebuilds every size-dependent table for a w x h input and uploads it.
+int set_geometry(orbx_ctx* c, int w, int h) {
+    if (w == c->cur_w && h == c->cur_h) return ORBX_OK;
+    std::vector<LevelGeom> levels;
+    std::vector<CellDesc> cells;
+    int rc = build_level_geometry(c->tab, w, h, &levels, &cells);
+    if (rc != ORBX_OK) return rc;
+    int cell_cap = 0, dense_total = 0, kp_total = 0, max_kp_level = 0;
+    size_t oct_lds = 0;
+    for (LevelGeom& g : levels) {
+        if (g.max_kp > 8192 || g.max_slots > 60000) return ORBX_E_GEOMETRY;
+        if (g.w_cell + 6 > kFastMaxCell - 1 || g.h_cell + 6 > kFastMaxCell - 1) return ORBX_E_GEOMETRY;
+        cell_cap = std::max(cell_cap, g.cell_cap);
+        max_kp_level = std::max(max_kp_level, g.max_kp);
+        oct_lds = std::max(oct_lds, oct_lds_bytes(g.max_slots, g.max_kp, g.n_cells));
+    }
+    if (oct_lds > 160 * 1024 - 256) return ORBX_E_GEOMETRY;
+    for (LevelGeom& g : levels) {
+        g.max_cand = g.n_cells * cell_cap;
+        dense_total += g.max_cand;
+        kp_total += g.max_kp;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    rc = ensure(c, &c->d_cells, cells.size() * sizeof(CellDesc));
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpy(c->d_cells.p, cells.data(), cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
+    for (int l = 0; l < c->tab.nlevels; ++l) {
+        c->pitch[l] = (int)align_up((size_t)levels[l].w, 64);
+        c->plane[l] = (size_t)c->pitch[l] * levels[l].h;
+        if (l == 0) continue;
+        std::vector<ResizeTap> xt, yt;
+        build_resize_taps(levels[l - 1].w, levels[l].w, true, &xt);
+        build_resize_taps(levels[l - 1].h, levels[l].h, false, &yt);
+        rc = ensure(c, &c->d_xt[l], xt.size() * sizeof(ResizeTap));
+        if (rc) return rc;
+        rc = ensure(c, &c->d_yt[l], yt.size() * sizeof(ResizeTap));
+        if (rc) return rc;
+        HIP_TRY(c, hipMemcpy(c->d_xt[l].p, xt.data(), xt.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_yt[l].p, yt.data(), yt.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
+    }
+    if (oct_lds > 64 * 1024) {
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)oct_lds));
+    }
+    c->levels.swap(levels);
+    c->cells.swap(cells);
+    c->cell_cap = cell_cap;
+    c->total_cells = (int)c->cells.size();
+    c->dense_total = dense_total;
+    c->kp_total = kp_total;
+    c->max_kp_level = max_kp_level;
+    c->oct_lds = oct_lds;
+    c->cur_w = w;
+    c->cur_h = h;
+    c->have_last = false;
+    return ORBX_OK;
+}
+
+int ensure_arenas(orbx_ctx* c, int n, bool need_level0) {
+    size_t pyr = 0, blur = 0;
+    for (int l = 0; l < c->tab.nlevels; ++l) {
+        if (l > 0 || need_level0) pyr += c->plane[l] * n;
+        blur += c->plane[l] * n;
+    }
+    int rc;
+    if ((rc = ensure(c, &c->d_pyr, pyr))) return rc;
+    if ((rc = ensure(c, &c->d_blur, blur))) return rc;
+    if ((rc = ensure(c, &c->d_cand, (size_t)n * c->total_cells * c->cell_cap * 4))) return rc;
+    if ((rc = ensure(c, &c->d_ccount, (size_t)n * c->total_cells * 4))) return rc;
+    if ((rc = ensure(c, &c->d_dense_pts, (size_t)n * c->dense_total * 4))) return rc;
+    if ((rc = ensure(c, &c->d_dense_node, (size_t)n * c->dense_total * 2))) return rc;
+    if ((rc = ensure(c, &c->d_lvl_kps, (size_t)n * c->kp_total * 4))) return rc;
+    if ((rc = ensure(c, &c->d_lvl_count, (size_t)n * c->tab.nlevels * 4))) return rc;
+    return ORBX_OK;
+}
+
+// Enqueues the whole path for n frames whose level 0 is at (l0, l0_pitch, l0_plane) in device memory.
+int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_plane, orbx_kp* d_kps, int kp_cap,
+              uint8_t* d_desc, int32_t* d_n_out) {
+    const int L = c->tab.nlevels;
+    BatchDev& B = c->B;
+    std::memset(&B, 0, sizeof(B));
+    B.nlevels = L;
+    B.nframes = n;
+    B.total_cells = c->total_cells;
+    B.cell_cap = c->cell_cap;
+    B.dense_total = c->dense_total;
+    B.kp_total = c->kp_total;
+    B.ini_th = c->prm.ini_th_fast;
+    B.min_th = c->prm.min_th_fast;
+    size_t poff = 0, boff = 0;
+    int dense_off = 0, kp_off = 0;
+    const bool l0_in_arena = (l0 == nullptr);
+    for (int l = 0; l < L; ++l) {
+        const LevelGeom& g = c->levels[l];
+        LevelDev& D = B.lv[l];
+        if (l == 0 && !l0_in_arena) {
+            D.img = l0;
+            D.pitch = l0_pitch;
+            D.plane = l0_plane;
+        } else {
+            D.img = (const uint8_t*)c->d_pyr.p + poff;
+            D.pitch = c->pitch[l];
+            D.plane = c->plane[l];
+            poff += c->plane[l] * n;
+        }
+        D.blur = (uint8_t*)c->d_blur.p + boff;
+        D.bpitch = c->pitch[l];
+        D.bplane = c->plane[l];
+        boff += c->plane[l] * n;
+        D.w = g.w;
+        D.h = g.h;
+        D.n_cells = g.n_cells;
+        D.cell_base = g.cell_base;
+        D.n_ini = g.n_ini;
+        D.h_x = g.h_x;
+        D.rect_w = g.rect_w;
+        D.rect_h = g.rect_h;
+        D.quota = g.quota;
+        D.max_kp = g.max_kp;
+        D.max_slots = g.max_slots;
+        D.dense_off = dense_off;
+        D.kp_off = kp_off;
+        D.scale = c->tab.scale[l];
+        D.size = (float)(int)(31 * c->tab.scale[l]);  // reference :930
+        dense_off += g.max_cand;
+        kp_off += g.max_kp;
+    }
+    hipStream_t st = c->stream;
+    const bool prof = c->profiling;
+    if (prof) HIP_TRY(c, hipEventRecord(c->ev[0], st));
+    // stage 0: pyramid
+    for (int l = 1; l < L; ++l) {
+        const LevelDev& S = B.lv[l - 1];
+        const LevelDev& D = B.lv[l];
+        dim3 grid((D.w + 255) / 256, (D.h + 3) / 4, n), block(64, 4);
+        hipLaunchKernelGGL(k_resize, grid, block, 0, st, S.img, S.pitch, S.plane, const_cast<uint8_t*>(D.img), D.pitch,
+                           D.plane, D.w, D.h, (const ResizeTap*)c->d_xt[l].p, (const ResizeTap*)c->d_yt[l].p);
+    }
+    if (prof) HIP_TRY(c, hipEventRecord(c->ev[1], st));
+    // stage 1: FAST cells
+    hipLaunchKernelGGL(k_fast_cells, dim3(c->total_cells, n), dim3(256), 0, st, B, (const CellDesc*)c->d_cells.p,
+                       (uint32_t*)c->d_cand.p, (uint32_t*)c->d_ccount.p);
+    if (prof) HIP_TRY(c, hipEventRecord(c->ev[2], st));
+    // stage 2: quadtree retention
+    hipLaunchKernelGGL(k_octree, dim3(L, n), dim3(256), c->oct_lds, st, B, (const uint32_t*)c->d_cand.p,
+                       (const uint32_t*)c->d_ccount.p, (uint32_t*)c->d_dense_pts.p, (uint16_t*)c->d_dense_node.p,
+                       (uint32_t*)c->d_lvl_kps.p, (int32_t*)c->d_lvl_count.p);
+    if (prof) HIP_TRY(c, hipEventRecord(c->ev[3], st));
+    // stage 3: blur
+    for (int l = 0; l < L; ++l) {
+        const LevelDev& D = B.lv[l];
+        dim3 grid((D.w + kBlurTW - 1) / kBlurTW, (D.h + kBlurTH - 1) / kBlurTH, n);
+        hipLaunchKernelGGL(k_blur7, grid, dim3(256), 0, st, D.img, D.pitch, D.plane, D.blur, D.bpitch, D.bplane, D.w, D.h);
+    }
+    if (prof) HIP_TRY(c, hipEventRecord(c->ev[4], st));
+    // stage 4: orientation + descriptors + output assembly
+    hipLaunchKernelGGL(k_orient_describe, dim3((c->max_kp_level + 3) / 4, L, n), dim3(256), 0, st, B,
+                       (const uint32_t*)c->d_lvl_kps.p, (const int32_t*)c->d_lvl_count.p, (const int8_t*)c->d_ic.p,
+                       (const int8_t*)c->d_pat.p, d_kps, d_desc, d_n_out, kp_cap);
+    if (prof) {
+        HIP_TRY(c, hipEventRecord(c->ev[5], st));
+        c->ev_valid = true;
+    }
+    HIP_TRY(c, hipGetLastError());
+    c->have_last = true;
+    return ORBX_OK;
+}
+
+int check_call(orbx_ctx* c, int n, int w, int h, int kp_cap) {
+    if (!c || n < 1 || w < 1 || h < 1) return ORBX_E_INVALID;
+    if (n > c->prm.max_batch || n > 65535) return ORBX_E_CAPACITY;
+    if (w > c->prm.max_width || h > c->prm.max_height) return ORBX_E_CAPACITY;
+    HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    int rc = set_geometry(c, w, h);
+    if (rc) return rc;
+    if (kp_cap < max_keypoints(c->levels)) return ORBX_E_CAPACITY;
+    return ORBX_OK;
+}
+
+}  // namespace
+
+// ---- C ABI ----------------------------------------------------------------------------------
+
+extern "C" int orbx_create(const orbx_params* params, orbx_ctx** out) {
+    if (!params || !out) return ORBX_E_INVALID;
+    *out = nullptr;
+    if (params->max_width < 1 || params->max_height < 1 || params->max_batch < 1) return ORBX_E_INVALID;
+    if (params->ini_th_fast < 0 || params->ini_th_fast > 255 || params->min_th_fast < 0 ||
+        params->min_th_fast > params->ini_th_fast)
+        return ORBX_E_INVALID;
+    Tables tab;
+    if (!build_tables(params->nfeatures, params->scale_factor, params->nlevels, &tab)) return ORBX_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return ORBX_E_NO_DEVICE;
+    if (params->device_id < 0 || params->device_id >= ndev) return ORBX_E_INVALID;
+    orbx_ctx* c = new (std::nothrow) orbx_ctx();
+    if (!c) return ORBX_E_INVALID;
+    c->prm = *params;
+    c->tab = tab;
+    int rc = ORBX_OK;
+    auto fail = [&](int code) {
+        orbx_destroy(c);
+        return code;
+    };
+    if (hipSetDevice(params->device_id) != hipSuccess) return fail(ORBX_E_HIP);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(ORBX_E_HIP);
+    for (int i = 0; i <= ORBX_NUM_STAGES; ++i)
+        if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(ORBX_E_HIP);
+    c->ev_made = true;
+    // orientation disc: (u, v) for every pixel with |u| <= umax[|v|]
+    std::vector<int8_t> ic;
+    for (int v = -kHalfPatch; v <= kHalfPatch; ++v)
+        for (int u = -tab.umax[std::abs(v)]; u <= tab.umax[std::abs(v)]; ++u) {
+            ic.push_back((int8_t)u);
+            ic.push_back((int8_t)v);
+        }
+    if ((int)ic.size() != 2 * kIcCount) return fail(ORBX_E_INVALID);
+    if ((rc = ensure(c, &c->d_ic, ic.size()))) return fail(rc);
+    if ((rc = ensure(c, &c->d_pat, sizeof(kPattern)))) return fail(rc);
+    if (hipMemcpy(c->d_ic.p, ic.data(), ic.size(), hipMemcpyHostToDevice) != hipSuccess) return fail(ORBX_E_HIP);
+    if (hipMemcpy(c->d_pat.p, kPattern, sizeof(kPattern), hipMemcpyHostToDevice) != hipSuccess) return fail(ORBX_E_HIP);
+    // size everything for the largest image and batch now, so steady-state calls do not allocate
+    if ((rc = set_geometry(c, params->max_width, params->max_height))) return fail(rc);
+    if ((rc = ensure_arenas(c, params->max_batch, true))) return fail(rc);
+    const int cap = max_keypoints(c->levels);
+    if ((rc = ensure(c, &c->d_out_kps, (size_t)params->max_batch * cap * sizeof(orbx_kp)))) return fail(rc);
+    if ((rc = ensure(c, &c->d_out_desc, (size_t)params->max_batch * cap * 32))) return fail(rc);
+    if ((rc = ensure(c, &c->d_out_n, (size_t)params->max_batch * 4))) return fail(rc);
+    *out = c;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_destroy(orbx_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->prm.device_id);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->d_cells, &c->d_ic, &c->d_pat, &c->d_pyr, &c->d_blur, &c->d_cand, &c->d_ccount,
+                      &c->d_dense_pts, &c->d_dense_node, &c->d_lvl_kps, &c->d_lvl_count, &c->d_out_kps,
+                      &c->d_out_desc, &c->d_out_n};
+    for (DevBuf* b : bufs) release(b);
+    for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
+        release(&c->d_xt[l]);
+        release(&c->d_yt[l]);
+    }
+    if (c->ev_made)
+        for (int i = 0; i <= ORBX_NUM_STAGES; ++i) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int orbx_extract_batch_device(orbx_ctx* c, int n, const uint8_t* d_imgs, int width, int height, int stride,
+                                         size_t frame_stride, orbx_kp* d_kps, int kp_cap, uint8_t* d_desc,
+                                         int32_t* d_n_out, int sync) {
+    if (!d_imgs || !d_kps || !d_desc || !d_n_out || stride < width) return ORBX_E_INVALID;
+    int rc = check_call(c, n, width, height, kp_cap);
+    if (rc) return rc;
+    const bool in_place = ((uintptr_t)d_imgs % 4 == 0) && (stride % 4 == 0) && (frame_stride % 4 == 0);
+    if ((rc = ensure_arenas(c, n, !in_place))) return rc;
+    if (!in_place) {
+        for (int i = 0; i < n; ++i)
+            HIP_TRY(c, hipMemcpy2DAsync((uint8_t*)c->d_pyr.p + (size_t)i * c->plane[0], c->pitch[0],
+                                        d_imgs + (size_t)i * frame_stride, stride, width, height,
+                                        hipMemcpyDeviceToDevice, c->stream));
+        rc = run_batch(c, n, nullptr, 0, 0, d_kps, kp_cap, d_desc, d_n_out);
+    } else {
+        rc = run_batch(c, n, d_imgs, stride, frame_stride, d_kps, kp_cap, d_desc, d_n_out);
+    }
+    if (rc) return rc;
+    if (sync) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_batch(orbx_ctx* c, int n, const uint8_t* const* imgs, int width, int height,
+                                  const int* strides, orbx_kp* kps, int kp_cap, uint8_t* desc, int* n_out) {
+    if (!imgs || !strides || !kps || !desc || !n_out) return ORBX_E_INVALID;
+    int rc = check_call(c, n, width, height, kp_cap);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i)
+        if (!imgs[i] || strides[i] < width) return ORBX_E_INVALID;
+    if ((rc = ensure_arenas(c, n, true))) return rc;
+    const int cap = max_keypoints(c->levels);
+    if ((rc = ensure(c, &c->d_out_kps, (size_t)n * cap * sizeof(orbx_kp)))) return rc;
+    if ((rc = ensure(c, &c->d_out_desc, (size_t)n * cap * 32))) return rc;
+    if ((rc = ensure(c, &c->d_out_n, (size_t)n * 4))) return rc;
+    for (int i = 0; i < n; ++i)
+        HIP_TRY(c, hipMemcpy2DAsync((uint8_t*)c->d_pyr.p + (size_t)i * c->plane[0], c->pitch[0], imgs[i], strides[i],
+                                    width, height, hipMemcpyHostToDevice, c->stream));
+    rc = run_batch(c, n, nullptr, 0, 0, (orbx_kp*)c->d_out_kps.p, cap, (uint8_t*)c->d_out_desc.p,
+                   (int32_t*)c->d_out_n.p);
+    if (rc) return rc;
+    std::vector<int32_t> cnt(n);
+    HIP_TRY(c, hipMemcpyAsync(cnt.data(), c->d_out_n.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; ++i) {
+        const int k = cnt[i];
+        n_out[i] = k;
+        if (k > 0) {
+            HIP_TRY(c, hipMemcpyAsync(kps + (size_t)i * kp_cap, (orbx_kp*)c->d_out_kps.p + (size_t)i * cap,
+                                      (size_t)k * sizeof(orbx_kp), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(desc + (size_t)i * kp_cap * 32, (uint8_t*)c->d_out_desc.p + (size_t)i * cap * 32,
+                                      (size_t)k * 32, hipMemcpyDeviceToHost, c->stream));
+        }
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract(orbx_ctx* c, const uint8_t* img, int width, int height, int stride, orbx_kp* kps,
+                            int kp_cap, uint8_t* desc, int* n_out) {
+    const uint8_t* imgs[1] = {img};
+    int strides[1] = {stride};
+    return orbx_extract_batch(c, 1, imgs, width, height, strides, kps, kp_cap, desc, n_out);
+}
+
+extern "C" int orbx_synchronize(orbx_ctx* c) {
+    if (!c) return ORBX_E_INVALID;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_pyramid_level(orbx_ctx* c, int img_idx, int level, uint8_t* dst, int dst_stride, int* width,
+                                  int* height) {
+    if (!c || !dst) return ORBX_E_INVALID;
+    if (!c->have_last) return ORBX_E_STATE;
+    if (img_idx < 0 || img_idx >= c->B.nframes || level < 0 || level >= c->B.nlevels) return ORBX_E_INVALID;
+    const LevelDev& D = c->B.lv[level];
+    if (dst_stride < D.w) return ORBX_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy2D(dst, dst_stride, D.img + (size_t)img_idx * D.plane, D.pitch, D.w, D.h, hipMemcpyDeviceToHost));
+    if (width) *width = D.w;
+    if (height) *height = D.h;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_debug_read(orbx_ctx* c, int what, int img_idx, int level, void* dst, size_t cap_bytes,
+                               size_t* n_bytes) {
+    if (!c || !dst || !n_bytes) return ORBX_E_INVALID;
+    if (!c->have_last) return ORBX_E_STATE;
+    if (img_idx < 0 || img_idx >= c->B.nframes || level < 0 || level >= c->B.nlevels) return ORBX_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const LevelDev& D = c->B.lv[level];
+    const BatchDev& B = c->B;
+    if (what == ORBX_DBG_BLURRED) {
+        *n_bytes = (size_t)D.w * D.h;
+        if (cap_bytes < *n_bytes) return ORBX_E_CAPACITY;
+        HIP_TRY(c, hipMemcpy2D(dst, D.w, D.blur + (size_t)img_idx * D.bplane, D.bpitch, D.w, D.h, hipMemcpyDeviceToHost));
+        return ORBX_OK;
+    }
+    if (what == ORBX_DBG_CANDIDATES) {
+        std::vector<uint32_t> cnt(D.n_cells);
+        const size_t slot0 = (size_t)img_idx * B.total_cells + D.cell_base;
+        HIP_TRY(c, hipMemcpy(cnt.data(), (uint32_t*)c->d_ccount.p + slot0, (size_t)D.n_cells * 4, hipMemcpyDeviceToHost));
+        size_t total = 0;
+        for (uint32_t v : cnt) total += v;
+        *n_bytes = total * 12;
+        if (cap_bytes < *n_bytes) return ORBX_E_CAPACITY;
+        std::vector<uint32_t> all((size_t)D.n_cells * B.cell_cap);
+        HIP_TRY(c, hipMemcpy(all.data(), (uint32_t*)c->d_cand.p + slot0 * B.cell_cap, all.size() * 4, hipMemcpyDeviceToHost));
+        int32_t* o = (int32_t*)dst;
+        for (int k = 0; k < D.n_cells; ++k)
+            for (uint32_t j = 0; j < cnt[k]; ++j) {
+                const uint32_t v = all[(size_t)k * B.cell_cap + j];
+                *o++ = pt_x(v);
+                *o++ = pt_y(v);
+                *o++ = pt_score(v);
+            }
+        return ORBX_OK;
+    }
+    if (what == ORBX_DBG_LEVEL_KPS) {
+        int32_t n = 0;
+        HIP_TRY(c, hipMemcpy(&n, (int32_t*)c->d_lvl_count.p + (size_t)img_idx * B.nlevels + level, 4, hipMemcpyDeviceToHost));
+        *n_bytes = (size_t)n * 12;
+        if (cap_bytes < *n_bytes) return ORBX_E_CAPACITY;
+        std::vector<uint32_t> v(n);
+        if (n)
+            HIP_TRY(c, hipMemcpy(v.data(), (uint32_t*)c->d_lvl_kps.p + (size_t)img_idx * B.kp_total + D.kp_off,
+                                 (size_t)n * 4, hipMemcpyDeviceToHost));
+        int32_t* o = (int32_t*)dst;
+        for (int i = 0; i < n; ++i) {
+            *o++ = pt_x(v[i]) + kBorder;
+            *o++ = pt_y(v[i]) + kBorder;
+            *o++ = pt_score(v[i]);
+        }
+        return ORBX_OK;
+    }
+    return ORBX_E_INVALID;
+}
+
+extern "C" int orbx_set_profiling(orbx_ctx* c, int enable) {
+    if (!c) return ORBX_E_INVALID;
+    c->profiling = enable != 0;
+    c->ev_valid = false;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_get_stage_ms(orbx_ctx* c, float ms[ORBX_NUM_STAGES]) {
+    if (!c || !ms) return ORBX_E_INVALID;
+    if (!c->ev_valid) return ORBX_E_STATE;
+    HIP_TRY(c, hipEventSynchronize(c->ev[ORBX_NUM_STAGES]));
+    for (int i = 0; i < ORBX_NUM_STAGES; ++i) HIP_TRY(c, hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+    return ORBX_OK;
+}
+
+extern "C" const char* orbx_stage_name(int stage) {
+    static const char* names[ORBX_NUM_STAGES] = {"pyramid", "fast", "quadtree", "blur", "orient_describe"};
+    return (stage >= 0 && stage < ORBX_NUM_STAGES) ? names[stage] : "?";
+}
+
+extern "C" const char* orbx_strerror(int code) {
+    switch (code) {
+        case ORBX_OK: return "ok";
+        case ORBX_E_INVALID: return "invalid argument";
+        case ORBX_E_HIP: return "HIP runtime error";
+        case ORBX_E_NO_DEVICE: return "no usable GPU";
+        case ORBX_E_CAPACITY: return "capacity exceeded";
+        case ORBX_E_GEOMETRY: return "image geometry not supported";
+        case ORBX_E_STATE: return "no extraction has run";
+        default: return "unknown error";
+    }
+}
+
+extern "C" int orbx_last_hip_error(const orbx_ctx* c) { return c ? c->last_hip : 0; }
+extern "C" const char* orbx_version(void) { return "orbx 0.1 (gfx950)"; }

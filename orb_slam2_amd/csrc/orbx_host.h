@@ -1,0 +1,69 @@
+// Host-side tables of the extractor: everything the reference computes once per instance or
+// once per image size, evaluated with the same float32/float64 operation order so that the
+// integer results (level sizes, quotas, cell grids, resize taps) are identical.
+#ifndef ORBX_HOST_H
+#define ORBX_HOST_H
+
+#include <cstdint>
+#include <vector>
+
+#include "../../include/orbx.h"
+
+namespace orbx {
+
+constexpr int kEdgeThreshold = 19;                  // reference src/ORBextractor.cc:75
+constexpr int kBorder = kEdgeThreshold - 3;         // 16: FAST rect origin (:862)
+constexpr int kHalfPatch = 15;                      // :74
+constexpr int kCellTarget = 30;                     // :858
+
+struct Tables {
+    int nlevels = 0;
+    float scale[ORBX_MAX_LEVELS], inv_scale[ORBX_MAX_LEVELS];
+    float sigma2[ORBX_MAX_LEVELS], inv_sigma2[ORBX_MAX_LEVELS];
+    int quota[ORBX_MAX_LEVELS];
+    int umax[16];
+};
+
+// One visited FAST cell (sub-image of a level), in visiting order.
+struct CellDesc {
+    int16_t x0, y0;      // sub-image origin in level coordinates
+    int16_t cw, ch;      // sub-image size (detection area is the interior minus a 3-px rim)
+    int16_t off_x, off_y;  // j*wCell, i*hCell: added to sub-image coords -> rect-relative coords
+    int16_t level;
+    int16_t pad;
+    int32_t slot;        // index of this cell's candidate slot (global over levels)
+    int32_t pad2;
+};
+static_assert(sizeof(CellDesc) == 24, "CellDesc layout");
+
+struct ResizeTap {  // one destination index of one axis
+    int16_t ofs;    // source index (clamped for columns; unclamped first row for rows)
+    int16_t ofs1;   // second source index, clamped into the image
+    int16_t c0, c1; // 11-bit fixed-point weights
+};
+static_assert(sizeof(ResizeTap) == 8, "ResizeTap layout");
+
+struct LevelGeom {
+    int w, h;
+    int n_cols, n_rows, w_cell, h_cell;
+    int n_cells;      // visited cells
+    int cell_base;    // first entry in the cell table
+    int n_ini;
+    float h_x;        // root width (float division, :578)
+    int rect_w, rect_h;
+    int quota;
+    int max_kp;       // upper bound on retained nodes
+    int max_slots;    // quadtree node slots needed
+    int cell_cap;     // candidate capacity of one cell of this level
+    int max_cand;     // upper bound on candidates of the level
+};
+
+bool build_tables(int nfeatures, float scale_factor, int nlevels, Tables* t);
+// Returns ORBX_OK or ORBX_E_GEOMETRY.
+int build_level_geometry(const Tables& t, int width, int height, std::vector<LevelGeom>* levels,
+                         std::vector<CellDesc>* cells);
+void build_resize_taps(int sn, int dn, bool clamp_index, std::vector<ResizeTap>* taps);
+int max_keypoints(const std::vector<LevelGeom>& levels);
+
+}  // namespace orbx
+#endif

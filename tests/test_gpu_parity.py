@@ -1,0 +1,129 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, stage by stage and end to end.
+
+Integer stages (pyramid, blur, FAST candidates, quadtree retention, descriptors) must be
+bit-exact; float outputs (angle, scaled coordinates) are produced by the same IEEE operation
+sequence on both sides and are compared bit-exactly too (tolerance 0).
+"""
+import numpy as np
+import pytest
+
+import orb_slam2_amd as oa
+from orb_slam2_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [
+    # (w, h, nfeatures, nlevels, config_id)
+    (640, 480, 1000, 8, 1),
+    (1241, 376, 2000, 8, 3),
+    (752, 480, 1200, 8, 4),
+    (317, 211, 500, 6, 7),
+]
+
+
+def _check_stages(ex, orc, img, idx=0):
+    nlev = ex.nlevels
+    for l in range(nlev):
+        got = ex.pyramid_level(idx, l)
+        assert got.shape == orc.level(l).shape
+        assert (got == orc.level(l)).all(), "pyramid level %d" % l
+    for l in range(nlev):
+        w, h = orc.level_dims(l)
+        got = ex.debug_read(oa.DBG_BLURRED, idx, l).reshape(h, w)
+        assert (got == orc.blurred(l)).all(), "blurred level %d" % l
+    for l in range(nlev):
+        got = ex.debug_read(oa.DBG_CANDIDATES, idx, l).view(np.int32).reshape(-1, 3)
+        exp = orc.candidates(l)
+        exp = np.stack([exp["x"], exp["y"], exp["response"]], 1)
+        assert got.shape == exp.shape, "candidate count level %d: %s vs %s" % (l, got.shape, exp.shape)
+        assert (got == exp).all(), "candidates level %d" % l
+
+
+def _check_final(kps, desc, okps, odesc):
+    assert len(kps) == len(okps)
+    for f in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+        assert (kps[f] == okps[f]).all(), f
+    assert (desc == odesc).all()
+
+
+@pytest.mark.parametrize("w,h,nf,nl,cid", CONFIGS)
+def test_single_frame_all_stages(oracle, w, h, nf, nl, cid):
+    img = synth.make_frame(w, h, cid, 0)
+    ex = oa.ORBextractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=1)
+    kps, desc = ex(img)
+    orc = oracle.Oracle(nf, 1.2, nl, 20, 7)
+    okps, odesc = orc.extract(img)
+    _check_stages(ex, orc, img)
+    for l in range(nl):
+        got = ex.debug_read(oa.DBG_LEVEL_KPS, 0, l).view(np.int32).reshape(-1, 3)
+        assert len(got) == orc.level_keypoint_count(l), "retained count level %d" % l
+    _check_final(kps, desc, okps, odesc)
+    # mvImagePyramid: level inside a 19-px reflect-101 border
+    for l in range(nl):
+        roi = ex.mvImagePyramid[l]
+        padded = roi.base if roi.base is not None else roi
+        assert (np.asarray(padded) == orc.padded_level(l)).all()
+    ex.close()
+
+
+def test_batch_matches_per_frame(oracle):
+    w, h, nf, nl = 752, 480, 1200, 8
+    n = 6
+    imgs = synth.make_batch(n, w, h, 4, 10)
+    ex = oa.ORBextractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=n)
+    res = ex.extract_batch(imgs)
+    orc = oracle.Oracle(nf, 1.2, nl, 20, 7)
+    for i in range(n):
+        okps, odesc = orc.extract(imgs[i])
+        _check_final(res[i][0], res[i][1], okps, odesc)
+    # intermediates of a frame in the middle of the batch
+    orc.extract(imgs[3])
+    _check_stages(ex, orc, imgs[3], idx=3)
+    ex.close()
+
+
+def test_strided_input_and_reuse(oracle):
+    w, h = 640, 480
+    big = np.zeros((h, w + 37), np.uint8)
+    big[:, :w] = synth.make_frame(w, h, 1, 5)
+    view = big[:, :w]
+    assert not view.flags["C_CONTIGUOUS"]
+    ex = oa.ORBextractor(1000, 1.2, 8, 20, 7, max_width=1241, max_height=480, max_batch=2)
+    orc = oracle.Oracle(1000, 1.2, 8, 20, 7)
+    kps, desc = ex(view)
+    _check_final(kps, desc, *orc.extract(view))
+    # same context, another size, then back
+    img2 = synth.make_frame(1241, 376, 3, 2)
+    _check_final(*ex(img2), *orc.extract(img2))
+    _check_final(*ex(view), *orc.extract(view))
+    ex.close()
+
+
+def test_flat_and_sparse_images(oracle):
+    w, h = 320, 240
+    ex = oa.ORBextractor(500, 1.2, 4, 20, 7, max_width=w, max_height=h)
+    orc = oracle.Oracle(500, 1.2, 4, 20, 7)
+    flat = np.full((h, w), 90, np.uint8)
+    kps, desc = ex(flat)
+    assert len(kps) == 0 and desc.shape == (0, 32)
+    assert len(orc.extract(flat)[0]) == 0
+    # a handful of isolated blobs: fewer candidates than the quota, min-threshold cells
+    sparse = flat.copy()
+    rng = np.random.default_rng(3)
+    for _ in range(25):
+        x, y = rng.integers(30, w - 30), rng.integers(30, h - 30)
+        sparse[y:y + 3, x:x + 3] = 90 + rng.integers(9, 120)
+    _check_final(*ex(sparse), *orc.extract(sparse))
+    assert ex(np.zeros((0, 0), np.uint8)) == (None, None)
+    ex.close()
+
+
+def test_errors():
+    ex = oa.ORBextractor(500, 1.2, 8, 20, 7, max_width=320, max_height=240)
+    with pytest.raises(oa.OrbxError):
+        ex(np.zeros((480, 640), np.uint8))          # larger than the context
+    with pytest.raises(oa.OrbxError):
+        ex(np.zeros((240, 320, 3), np.uint8))       # not single channel
+    with pytest.raises(oa.OrbxError):
+        ex(np.zeros((100, 100), np.uint8))          # top level too small for a 30-px cell grid
+    ex.close()
