@@ -50,52 +50,112 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 }
 
 // cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) on 8UC1, OpenCV 3.4.5 fixed-point path:
-// taps 18,34,49,55,49,34,18 (/256, sum 257); row pass exact in u16; column pass
+// taps 18,34,49,55,49,34,18 (/256, sum 257); row pass exact (<= 65535); column pass
 // min(255, (sum + 32768) >> 16).
-// One workgroup blurs a 64x32 tile: stage 70x38 source bytes (reflected at the level's own
-// borders), row pass into a 64x38 u16 tile, column pass from LDS, dword stores.
-// grid = (ceil(w/64), ceil(h/32), frames), block = 256.
-constexpr int kBlurTW = 64, kBlurTH = 32;
-__global__ __launch_bounds__(256) void k_blur7(const uint8_t* __restrict__ src, int spitch, uint64_t splane,
-                                               uint8_t* __restrict__ dst, int dpitch, uint64_t dplane,
-                                               int w, int h) {
-    __shared__ uint8_t s_in[kBlurTH + 6][kBlurTW + 8];     // 38 x 72
-    __shared__ uint16_t s_row[kBlurTH + 6][kBlurTW];       // 38 x 64
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * kBlurTW, y0 = blockIdx.y * kBlurTH;
-    const uint8_t* S = src + (uint64_t)blockIdx.z * splane;
-    for (int i = tid; i < (kBlurTH + 6) * (kBlurTW + 6); i += 256) {
-        const int r = i / (kBlurTW + 6), c = i - r * (kBlurTW + 6);
-        const int yy = reflect101(min(y0 + r - 3, h + 2), h);
-        const int xx = reflect101(min(x0 + c - 3, w + 2), w);
-        s_in[r][c] = S[(uint64_t)yy * spitch + xx];
-    }
-    __syncthreads();
-    for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const uint8_t* p = &s_in[r][c];
-        const int v = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
-        s_row[r][c] = (uint16_t)v;
-    }
-    __syncthreads();
-    uint8_t* D = dst + (uint64_t)blockIdx.z * dplane;
-    for (int i = tid; i < kBlurTH * (kBlurTW / 4); i += 256) {
-        const int r = i >> 4, c = (i & 15) * 4;
-        const int y = y0 + r, x = x0 + c;
-        if (y >= h || x >= w) continue;
-        uint32_t out = 0;
+//
+// Streaming form: no LDS, register sliding window.  A thread owns four adjacent columns and walks
+// down kBlurRows output rows.  Per source row it loads three aligned dwords (pixels x0-4 .. x0+7,
+// kBlurPF rows ahead of their use), forms the four row sums with v_alignbyte_b32 + v_dot4_u32_u8
+// (taps 18,34,49,55 | 49,34,18,0), keeps the last seven row sums per column in registers and
+// stores one dword per row.  Rows are reflected by index (wave-uniform, scalar arithmetic).
+// Dwords holding a column whose 7-tap window leaves the image (columns [0,4) and the last 3..6)
+// are not stored by the streaming blocks; the extra "edge" block column
+// (blockIdx.x == gridDim.x-1) computes them through a small LDS tile of row sums.
+// grid = (ceil(w/256) + 1, ceil(h / (4*kBlurRows)), frames), block = (64, 4).
+constexpr int kBlurRows = 32;
+constexpr int kBlurPF = 4;
+
+__device__ __forceinline__ uint32_t blur_col(const uint32_t (&wn)[7][4], int r, int k) {
+    // window rows r-6 .. r live in slots (r-6)%7 .. r%7
+    // 24-bit multiplies (full rate): every operand is below 2^18
+    const uint32_t v = __umul24(18u, wn[(r + 1) % 7][k] + wn[r % 7][k]) + __umul24(34u, wn[(r + 2) % 7][k] + wn[(r + 6) % 7][k]) +
+                       __umul24(49u, wn[(r + 3) % 7][k] + wn[(r + 5) % 7][k]) + __umul24(55u, wn[(r + 4) % 7][k]);
+    return min(255u, (v + 32768u) >> 16);
+}
+
+__device__ __forceinline__ uint32_t gauss_tap(int j) {
+    const int k = j < 4 ? j : 6 - j;
+    return k == 0 ? 18u : k == 1 ? 34u : k == 2 ? 49u : 55u;
+}
+
+__global__ __launch_bounds__(256) void k_blur7_stream(const uint8_t* __restrict__ src, int spitch, uint64_t splane,
+                                                      uint8_t* __restrict__ dst, int dpitch, uint64_t dplane,
+                                                      int w, int h) {
+    const uint8_t* S8 = src + (uint64_t)blockIdx.z * splane;
+    uint8_t* D8 = dst + (uint64_t)blockIdx.z * dplane;
+    // streaming lanes store dwords x0 in [4, last_full]; the edge block owns [0,4) and [xs, w)
+    const int last_full = ((w - 7) >> 2) << 2;
+    const int xs = last_full + 4;
+    if (blockIdx.x == gridDim.x - 1) {
+        constexpr int kRows = 4 * kBlurRows;                 // output rows per block
+        __shared__ uint16_t s_sum[kRows + 6][10];
+        const int tid = threadIdx.y * 64 + threadIdx.x;
+        const int yb = blockIdx.y * kRows;
+        const int nright = w - xs;                           // 3..6
+        if (tid < kRows + 6) {
+            const int yy = reflect101(min(yb + tid - 3, h + 2), h);
+            const uint8_t* row = S8 + (uint64_t)yy * spitch;
+            for (int e = 0; e < 10; ++e) {
+                const int x = e < 4 ? e : xs + (e - 4);
+                uint32_t rs = 0;
+                if (e < 4 + nright) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t v = 18u * (s_row[r][c + k] + s_row[r + 6][c + k]) +
-                               34u * (s_row[r + 1][c + k] + s_row[r + 5][c + k]) +
-                               49u * (s_row[r + 2][c + k] + s_row[r + 4][c + k]) + 55u * s_row[r + 3][c + k];
-            out |= min(255u, (v + 32768u) >> 16) << (8 * k);
+                    for (int t = 0; t < 7; ++t) rs += gauss_tap(t) * row[reflect101(x + t - 3, w)];
+                }
+                s_sum[tid][e] = (uint16_t)rs;
+            }
         }
-        uint8_t* d = D + (uint64_t)y * dpitch + x;
-        if (x + 3 < w) {
-            *reinterpret_cast<uint32_t*>(d) = out;
-        } else {
-            for (int k = 0; x + k < w; ++k) d[k] = (uint8_t)(out >> (8 * k));
+        __syncthreads();
+        if (tid < kRows && yb + tid < h) {
+            uint8_t* drow = D8 + (uint64_t)(yb + tid) * dpitch;
+            for (int e = 0; e < 4 + nright; ++e) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) acc += gauss_tap(j) * s_sum[tid + j][e];
+                drow[e < 4 ? e : xs + (e - 4)] = (uint8_t)min(255u, (acc + 32768u) >> 16);
+            }
+        }
+        return;
+    }
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * kBlurRows;
+    if (y0 >= h) return;  // wave-uniform
+    const int ndw = spitch >> 2;
+    const int c1 = min(x0 >> 2, ndw - 1), c0 = max(c1 - 1, 0), c2 = min(c1 + 1, ndw - 1);
+    const uint32_t* S = reinterpret_cast<const uint32_t*>(S8);
+    const bool store_ok = x0 >= 4 && x0 <= last_full;
+    uint32_t* D = reinterpret_cast<uint32_t*>(D8) + (x0 >> 2);
+    const int ddw = dpitch >> 2;
+    uint32_t qL[kBlurPF], qC[kBlurPF], qR[kBlurPF];
+#pragma unroll
+    for (int r = 0; r < kBlurPF; ++r) {
+        const uint32_t* row = S + (uint64_t)reflect101(min(y0 + r - 3, h + 2), h) * ndw;
+        qL[r] = row[c0];
+        qC[r] = row[c1];
+        qR[r] = row[c2];
+    }
+    uint32_t wn[7][4];
+#pragma unroll
+    for (int r = 0; r < kBlurRows + 6; ++r) {
+        const uint32_t L = qL[r % kBlurPF], C = qC[r % kBlurPF], R = qR[r % kBlurPF];
+        if (r + kBlurPF < kBlurRows + 6) {
+            const uint32_t* row = S + (uint64_t)reflect101(min(y0 + r + kBlurPF - 3, h + 2), h) * ndw;
+            qL[r % kBlurPF] = row[c0];
+            qC[r % kBlurPF] = row[c1];
+            qR[r % kBlurPF] = row[c2];
+        }
+        const uint32_t a0 = __builtin_amdgcn_alignbyte(C, L, 1), b0 = __builtin_amdgcn_alignbyte(R, C, 1);
+        const uint32_t a1 = __builtin_amdgcn_alignbyte(C, L, 2), b1 = __builtin_amdgcn_alignbyte(R, C, 2);
+        const uint32_t a2 = __builtin_amdgcn_alignbyte(C, L, 3), b2 = __builtin_amdgcn_alignbyte(R, C, 3);
+        wn[r % 7][0] = __builtin_amdgcn_udot4(b0, 0x00122231u, __builtin_amdgcn_udot4(a0, 0x37312212u, 0u, false), false);
+        wn[r % 7][1] = __builtin_amdgcn_udot4(b1, 0x00122231u, __builtin_amdgcn_udot4(a1, 0x37312212u, 0u, false), false);
+        wn[r % 7][2] = __builtin_amdgcn_udot4(b2, 0x00122231u, __builtin_amdgcn_udot4(a2, 0x37312212u, 0u, false), false);
+        wn[r % 7][3] = __builtin_amdgcn_udot4(R, 0x00122231u, __builtin_amdgcn_udot4(C, 0x37312212u, 0u, false), false);
+        if (r >= 6) {
+            const int y = y0 + r - 6;  // wave-uniform
+            const uint32_t o = blur_col(wn, r, 0) | (blur_col(wn, r, 1) << 8) | (blur_col(wn, r, 2) << 16) |
+                               (blur_col(wn, r, 3) << 24);
+            if (y < h && store_ok) D[(uint64_t)y * ddw] = o;
         }
     }
 }

@@ -42,13 +42,16 @@ struct orbx_ctx {
     int cur_w = -1, cur_h = -1;
     std::vector<LevelGeom> levels;
     std::vector<CellDesc> cells;
+    std::vector<TileDesc> tiles;
+    int fast_tile_bytes = 0, fast_plane_bytes = 0;
+    size_t fast_lds = 0;
     int pitch[ORBX_MAX_LEVELS];
     size_t plane[ORBX_MAX_LEVELS];
     int cell_cap = 0, total_cells = 0, dense_total = 0, kp_total = 0, max_kp_level = 0;
     size_t oct_lds = 0;
 
     // device tables
-    DevBuf d_cells, d_ic, d_pat;
+    DevBuf d_cells, d_tiles, d_ic, d_pat;
     DevBuf d_xt[ORBX_MAX_LEVELS], d_yt[ORBX_MAX_LEVELS];
     // device arenas (grown on demand)
     DevBuf d_pyr, d_blur, d_cand, d_ccount, d_dense_pts, d_dense_node, d_lvl_kps, d_lvl_count;
@@ -117,10 +120,30 @@ int set_geometry(orbx_ctx* c, int w, int h) {
         dense_total += g.max_cand;
         kp_total += g.max_kp;
     }
+    std::vector<TileDesc> tiles;
+    build_fast_tiles(levels, cells, &tiles);
+    int tile_b = 0, plane_b = 0, queue_b = 0;
+    for (const TileDesc& t : tiles) {
+        const FastLds need = fast_lds_need(t.x_first, t.wd, t.hd, t.nc);
+        tile_b = std::max(tile_b, need.tile);
+        plane_b = std::max(plane_b, need.plane);
+        queue_b = std::max(queue_b, need.queue);
+    }
+    tile_b = (int)align_up((size_t)tile_b, 16);
+    plane_b = (int)align_up((size_t)plane_b, 16);
+    const size_t fast_lds = (size_t)tile_b + 2 * (size_t)plane_b + (size_t)queue_b + 16;
+    if (fast_lds > 160 * 1024 - 256) return ORBX_E_GEOMETRY;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     rc = ensure(c, &c->d_cells, cells.size() * sizeof(CellDesc));
     if (rc) return rc;
     HIP_TRY(c, hipMemcpy(c->d_cells.p, cells.data(), cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
+    rc = ensure(c, &c->d_tiles, tiles.size() * sizeof(TileDesc));
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpy(c->d_tiles.p, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+    if (fast_lds > 64 * 1024) {
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_tiles),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_lds));
+    }
     for (int l = 0; l < c->tab.nlevels; ++l) {
         c->pitch[l] = (int)align_up((size_t)levels[l].w, 64);
         c->plane[l] = (size_t)c->pitch[l] * levels[l].h;
@@ -141,6 +164,10 @@ int set_geometry(orbx_ctx* c, int w, int h) {
     }
     c->levels.swap(levels);
     c->cells.swap(cells);
+    c->tiles.swap(tiles);
+    c->fast_tile_bytes = tile_b;
+    c->fast_plane_bytes = plane_b;
+    c->fast_lds = fast_lds;
     c->cell_cap = cell_cap;
     c->total_cells = (int)c->cells.size();
     c->dense_total = dense_total;
@@ -236,8 +263,9 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     }
     if (prof) HIP_TRY(c, hipEventRecord(c->ev[1], st));
     // stage 1: FAST cells
-    hipLaunchKernelGGL(k_fast_cells, dim3(c->total_cells, n), dim3(256), 0, st, B, (const CellDesc*)c->d_cells.p,
-                       (uint32_t*)c->d_cand.p, (uint32_t*)c->d_ccount.p);
+    hipLaunchKernelGGL(k_fast_tiles, dim3((unsigned)c->tiles.size(), n), dim3(256), c->fast_lds, st, B,
+                       (const TileDesc*)c->d_tiles.p, (uint32_t*)c->d_cand.p, (uint32_t*)c->d_ccount.p,
+                       c->fast_tile_bytes, c->fast_plane_bytes);
     if (prof) HIP_TRY(c, hipEventRecord(c->ev[2], st));
     // stage 2: quadtree retention
     hipLaunchKernelGGL(k_octree, dim3(L, n), dim3(256), c->oct_lds, st, B, (const uint32_t*)c->d_cand.p,
@@ -247,8 +275,8 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     // stage 3: blur
     for (int l = 0; l < L; ++l) {
         const LevelDev& D = B.lv[l];
-        dim3 grid((D.w + kBlurTW - 1) / kBlurTW, (D.h + kBlurTH - 1) / kBlurTH, n);
-        hipLaunchKernelGGL(k_blur7, grid, dim3(256), 0, st, D.img, D.pitch, D.plane, D.blur, D.bpitch, D.bplane, D.w, D.h);
+        dim3 grid((D.w + 255) / 256 + 1, (D.h + 4 * kBlurRows - 1) / (4 * kBlurRows), n);
+        hipLaunchKernelGGL(k_blur7_stream, grid, dim3(64, 4), 0, st, D.img, D.pitch, D.plane, D.blur, D.bpitch, D.bplane, D.w, D.h);
     }
     if (prof) HIP_TRY(c, hipEventRecord(c->ev[4], st));
     // stage 4: orientation + descriptors + output assembly
@@ -332,7 +360,7 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->prm.device_id);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->d_cells, &c->d_ic, &c->d_pat, &c->d_pyr, &c->d_blur, &c->d_cand, &c->d_ccount,
+    DevBuf* bufs[] = {&c->d_cells, &c->d_tiles, &c->d_ic, &c->d_pat, &c->d_pyr, &c->d_blur, &c->d_cand, &c->d_ccount,
                       &c->d_dense_pts, &c->d_dense_node, &c->d_lvl_kps, &c->d_lvl_count, &c->d_out_kps,
                       &c->d_out_desc, &c->d_out_n};
     for (DevBuf* b : bufs) release(b);

@@ -114,6 +114,36 @@ int build_level_geometry(const Tables& t, int width, int height, std::vector<Lev
     return ORBX_OK;
 }
 
+// Cells of one cell row are consecutive in the cell list and their detection areas
+// [x0+3, x0+cw-3) x [y0+3, y0+ch-3) tile the row without gaps, so a run of cells is one rectangle.
+void build_fast_tiles(const std::vector<LevelGeom>& levels, const std::vector<CellDesc>& cells,
+                      std::vector<TileDesc>* tiles) {
+    tiles->clear();
+    size_t k = 0;
+    while (k < cells.size()) {
+        const CellDesc& first = cells[k];
+        size_t e = k + 1;
+        while (e < cells.size() && e - k < (size_t)kFastTileCells && cells[e].level == first.level &&
+               cells[e].y0 == first.y0)
+            ++e;
+        const CellDesc& last = cells[e - 1];
+        TileDesc t;
+        std::memset(&t, 0, sizeof(t));
+        t.level = first.level;
+        t.nc = (int16_t)(e - k);
+        t.x_first = (int16_t)(first.x0 + 3);
+        t.y_first = (int16_t)(first.y0 + 3);
+        t.wd = (int16_t)((last.x0 + last.cw - 3) - (first.x0 + 3));
+        t.hd = (int16_t)(first.ch - 6);
+        t.w_cell = (int16_t)levels[first.level].w_cell;
+        t.slot0 = first.slot;
+        t.off_x = (int16_t)(first.off_x + 3);
+        t.off_y = (int16_t)(first.off_y + 3);
+        tiles->push_back(t);
+        k = e;
+    }
+}
+
 // cv::resize(..., INTER_LINEAR) 8UC1 tap setup, OpenCV 3.4.5 (reference call site :1237):
 // scale = 1/(dn/sn) in double, f = float((d+0.5)*scale-0.5), index = floor(f), weight = f-index
 // in float, 11-bit weights rounded half to even.

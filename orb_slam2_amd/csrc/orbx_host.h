@@ -36,6 +36,22 @@ struct CellDesc {
 };
 static_assert(sizeof(CellDesc) == 24, "CellDesc layout");
 
+// One FAST work tile: up to kFastTileCells horizontally adjacent cells of one cell row.
+// Detection coordinates (u, v) run over the union of the cells' detection areas.
+struct TileDesc {
+    int16_t level;
+    int16_t nc;          // cells in the tile
+    int16_t x_first;     // level x of detection column u = 0 (= 19 + j0*wCell)
+    int16_t y_first;     // level y of detection row v = 0 (= 19 + i*hCell)
+    int16_t wd, hd;      // detection width (all cells) and height
+    int16_t w_cell;      // width of every cell but possibly the last
+    int16_t pad;
+    int32_t slot0;       // candidate slot of the first cell; the others follow
+    int16_t off_x, off_y;  // rect-relative coordinates of (u, v) = (0, 0): j0*wCell + 3, i*hCell + 3
+};
+static_assert(sizeof(TileDesc) == 24, "TileDesc layout");
+constexpr int kFastTileCells = 4;
+
 struct ResizeTap {  // one destination index of one axis
     int16_t ofs;    // source index (clamped for columns; unclamped first row for rows)
     int16_t ofs1;   // second source index, clamped into the image
@@ -62,6 +78,9 @@ bool build_tables(int nfeatures, float scale_factor, int nlevels, Tables* t);
 // Returns ORBX_OK or ORBX_E_GEOMETRY.
 int build_level_geometry(const Tables& t, int width, int height, std::vector<LevelGeom>* levels,
                          std::vector<CellDesc>* cells);
+// Groups the visited cells (as listed by build_level_geometry) into FAST work tiles.
+void build_fast_tiles(const std::vector<LevelGeom>& levels, const std::vector<CellDesc>& cells,
+                      std::vector<TileDesc>* tiles);
 void build_resize_taps(int sn, int dn, bool clamp_index, std::vector<ResizeTap>* taps);
 int max_keypoints(const std::vector<LevelGeom>& levels);
 
