@@ -53,24 +53,34 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // taps 18,34,49,55,49,34,18 (/256, sum 257); row pass exact (<= 65535); column pass
 // min(255, (sum + 32768) >> 16).
 //
-// Streaming form: no LDS, register sliding window.  A thread owns four adjacent columns and walks
-// down kBlurRows output rows.  Per source row it loads three aligned dwords (pixels x0-4 .. x0+7,
-// kBlurPF rows ahead of their use), forms the four row sums with v_alignbyte_b32 + v_dot4_u32_u8
-// (taps 18,34,49,55 | 49,34,18,0), keeps the last seven row sums per column in registers and
-// stores one dword per row.  Rows are reflected by index (wave-uniform, scalar arithmetic).
-// Dwords holding a column whose 7-tap window leaves the image (columns [0,4) and the last 3..6)
-// are not stored by the streaming blocks; the extra "edge" block column
-// (blockIdx.x == gridDim.x-1) computes them through a small LDS tile of row sums.
-// grid = (ceil(w/256) + 1, ceil(h / (4*kBlurRows)), frames), block = (64, 4).
+// Streaming form, all levels and frames in one launch: no LDS, register sliding window.
+// A level is cut into row tiles of kBlurRows rows; the (row tile, dword column) pairs of a level
+// are numbered linearly and dealt to lanes, so no lane idles at a strip end.  A lane owns four
+// adjacent columns of its row tile and walks down it: per source row it loads three aligned
+// dwords (pixels x0-4 .. x0+7, kBlurPF rows ahead of their use) through a buffer resource, forms
+// the four row sums with v_alignbyte_b32 + v_dot4_u32_u8 (taps 18,34,49,55 | 49,34,18,0), keeps
+// the row sums of the last six rows packed in pairs and evaluates the column pass with
+// v_dot2_u32_u16, storing one dword per row.  Rows are reflected by index.  Dwords holding a
+// column whose 7-tap window leaves the image (columns [0,4) and the last 3..6) are not stored by
+// streaming lanes (their store offset is pushed out of the buffer's range); "edge" blocks compute
+// those columns through a small LDS tile of row sums.
+// grid = (B.blur_first[nlevels], frames), block = 256.
 constexpr int kBlurRows = 32;
 constexpr int kBlurPF = 4;
+constexpr int kBlurEdgeRows = 128;  // output rows per edge block
 
-__device__ __forceinline__ uint32_t blur_col(const uint32_t (&wn)[7][4], int r, int k) {
-    // window rows r-6 .. r live in slots (r-6)%7 .. r%7
-    // 24-bit multiplies (full rate): every operand is below 2^18
-    const uint32_t v = __umul24(18u, wn[(r + 1) % 7][k] + wn[r % 7][k]) + __umul24(34u, wn[(r + 2) % 7][k] + wn[(r + 6) % 7][k]) +
-                       __umul24(49u, wn[(r + 3) % 7][k] + wn[(r + 5) % 7][k]) + __umul24(55u, wn[(r + 4) % 7][k]);
-    return min(255u, (v + 32768u) >> 16);
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t taps, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, taps), c, false);
+}
+// Column pass for one pixel at row r.  pr[j % 6] holds the row sums of rows (j, j+1) packed as
+// two u16; the window rows r-6 .. r are pr[(r-6)%6], pr[(r-4)%6], pr[(r-2)%6] and the fresh sum.
+__device__ __forceinline__ uint32_t blur_col(const uint32_t (&pr)[6][4], uint32_t w_r, int r, int k) {
+    uint32_t v = __umul24(18u, w_r) + 32768u;
+    v = udot2(pr[(r + 4) % 6][k], 49u | (34u << 16), v);  // rows r-2, r-1
+    v = udot2(pr[(r + 2) % 6][k], 49u | (55u << 16), v);  // rows r-4, r-3
+    v = udot2(pr[r % 6][k], 18u | (34u << 16), v);        // rows r-6, r-5
+    return min(255u, v >> 16);
 }
 
 __device__ __forceinline__ uint32_t gauss_tap(int j) {
@@ -78,21 +88,31 @@ __device__ __forceinline__ uint32_t gauss_tap(int j) {
     return k == 0 ? 18u : k == 1 ? 34u : k == 2 ? 49u : 55u;
 }
 
-__global__ __launch_bounds__(256) void k_blur7_stream(const uint8_t* __restrict__ src, int spitch, uint64_t splane,
-                                                      uint8_t* __restrict__ dst, int dpitch, uint64_t dplane,
-                                                      int w, int h) {
-    const uint8_t* S8 = src + (uint64_t)blockIdx.z * splane;
-    uint8_t* D8 = dst + (uint64_t)blockIdx.z * dplane;
-    // streaming lanes store dwords x0 in [4, last_full]; the edge block owns [0,4) and [xs, w)
+// Block counts of one level: streaming blocks, then edge blocks.
+__host__ __device__ inline int blur_main_blocks(int w, int h) {
+    const int nd = (w + 3) >> 2, nty = (h + kBlurRows - 1) / kBlurRows;
+    return (nd * nty + 255) >> 8;
+}
+__host__ __device__ inline int blur_edge_blocks(int h) { return (h + kBlurEdgeRows - 1) / kBlurEdgeRows; }
+
+__global__ __launch_bounds__(256) void k_blur7_all(BatchDev B) {
+    int level = 0;
+    while (level + 1 < B.nlevels && (int)blockIdx.x >= B.blur_first[level + 1]) ++level;
+    const LevelDev& L = B.lv[level];
+    const int blk = blockIdx.x - B.blur_first[level];
+    const int w = L.w, h = L.h, spitch = L.pitch, dpitch = L.bpitch;
+    const uint8_t* S8 = L.img + (uint64_t)blockIdx.y * L.plane;
+    uint8_t* D8 = L.blur + (uint64_t)blockIdx.y * L.bplane;
+    const int tid = threadIdx.x;
+    // streaming lanes store dwords x0 in [4, last_full]; edge blocks own [0,4) and [xs, w)
     const int last_full = ((w - 7) >> 2) << 2;
     const int xs = last_full + 4;
-    if (blockIdx.x == gridDim.x - 1) {
-        constexpr int kRows = 4 * kBlurRows;                 // output rows per block
-        __shared__ uint16_t s_sum[kRows + 6][10];
-        const int tid = threadIdx.y * 64 + threadIdx.x;
-        const int yb = blockIdx.y * kRows;
-        const int nright = w - xs;                           // 3..6
-        if (tid < kRows + 6) {
+    const int nmain = blur_main_blocks(w, h);
+    if (blk >= nmain) {
+        __shared__ uint16_t s_sum[kBlurEdgeRows + 6][10];
+        const int yb = (blk - nmain) * kBlurEdgeRows;
+        const int nright = w - xs;  // 3..6
+        if (tid < kBlurEdgeRows + 6) {
             const int yy = reflect101(min(yb + tid - 3, h + 2), h);
             const uint8_t* row = S8 + (uint64_t)yy * spitch;
             for (int e = 0; e < 10; ++e) {
@@ -106,7 +126,7 @@ __global__ __launch_bounds__(256) void k_blur7_stream(const uint8_t* __restrict_
             }
         }
         __syncthreads();
-        if (tid < kRows && yb + tid < h) {
+        if (tid < kBlurEdgeRows && yb + tid < h) {
             uint8_t* drow = D8 + (uint64_t)(yb + tid) * dpitch;
             for (int e = 0; e < 4 + nright; ++e) {
                 uint32_t acc = 0;
@@ -117,45 +137,57 @@ __global__ __launch_bounds__(256) void k_blur7_stream(const uint8_t* __restrict_
         }
         return;
     }
-    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int y0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y)) * kBlurRows;
-    if (y0 >= h) return;  // wave-uniform
-    const int ndw = spitch >> 2;
-    const int c1 = min(x0 >> 2, ndw - 1), c0 = max(c1 - 1, 0), c2 = min(c1 + 1, ndw - 1);
-    const uint32_t* S = reinterpret_cast<const uint32_t*>(S8);
-    const bool store_ok = x0 >= 4 && x0 <= last_full;
-    uint32_t* D = reinterpret_cast<uint32_t*>(D8) + (x0 >> 2);
-    const int ddw = dpitch >> 2;
+    const int nd = (w + 3) >> 2, nty = (h + kBlurRows - 1) / kBlurRows;
+    const int g = blk * 256 + tid;
+    const int ty = (int)(((float)g + 0.5f) * (1.0f / (float)nd));  // g / nd, exact for g < 2^22
+    const int dcol = g - ty * nd;
+    const bool live = ty < nty;
+    const int x0 = dcol * 4;
+    const int y0 = ty * kBlurRows;
+    // Buffer addressing: out-of-range accesses (column -4 of the first lane of row 0, idle lanes,
+    // lanes that own no full dword) are dropped by the hardware range check.
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(S8), 0, h * spitch, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(D8, 0, h * dpitch, 0x00020000);
+    const int kOut = 0x7FFFFFF0;
+    const bool store_ok = live && x0 >= 4 && x0 <= last_full;
+    const int vcol = live ? x0 - 4 : kOut;
     uint32_t qL[kBlurPF], qC[kBlurPF], qR[kBlurPF];
 #pragma unroll
     for (int r = 0; r < kBlurPF; ++r) {
-        const uint32_t* row = S + (uint64_t)reflect101(min(y0 + r - 3, h + 2), h) * ndw;
-        qL[r] = row[c0];
-        qC[r] = row[c1];
-        qR[r] = row[c2];
+        const int vo = reflect101(min(y0 + r - 3, h + 2), h) * spitch + vcol;
+        qL[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0, 0);
+        qC[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo + 4, 0, 0);
+        qR[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo + 8, 0, 0);
     }
-    uint32_t wn[7][4];
+    uint32_t pr[6][4], wp[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < kBlurRows + 6; ++r) {
-        const uint32_t L = qL[r % kBlurPF], C = qC[r % kBlurPF], R = qR[r % kBlurPF];
+        const uint32_t Lw = qL[r % kBlurPF], C = qC[r % kBlurPF], R = qR[r % kBlurPF];
         if (r + kBlurPF < kBlurRows + 6) {
-            const uint32_t* row = S + (uint64_t)reflect101(min(y0 + r + kBlurPF - 3, h + 2), h) * ndw;
-            qL[r % kBlurPF] = row[c0];
-            qC[r % kBlurPF] = row[c1];
-            qR[r % kBlurPF] = row[c2];
+            const int vo = reflect101(min(y0 + r + kBlurPF - 3, h + 2), h) * spitch + vcol;
+            qL[r % kBlurPF] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0, 0);
+            qC[r % kBlurPF] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo + 4, 0, 0);
+            qR[r % kBlurPF] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo + 8, 0, 0);
         }
-        const uint32_t a0 = __builtin_amdgcn_alignbyte(C, L, 1), b0 = __builtin_amdgcn_alignbyte(R, C, 1);
-        const uint32_t a1 = __builtin_amdgcn_alignbyte(C, L, 2), b1 = __builtin_amdgcn_alignbyte(R, C, 2);
-        const uint32_t a2 = __builtin_amdgcn_alignbyte(C, L, 3), b2 = __builtin_amdgcn_alignbyte(R, C, 3);
-        wn[r % 7][0] = __builtin_amdgcn_udot4(b0, 0x00122231u, __builtin_amdgcn_udot4(a0, 0x37312212u, 0u, false), false);
-        wn[r % 7][1] = __builtin_amdgcn_udot4(b1, 0x00122231u, __builtin_amdgcn_udot4(a1, 0x37312212u, 0u, false), false);
-        wn[r % 7][2] = __builtin_amdgcn_udot4(b2, 0x00122231u, __builtin_amdgcn_udot4(a2, 0x37312212u, 0u, false), false);
-        wn[r % 7][3] = __builtin_amdgcn_udot4(R, 0x00122231u, __builtin_amdgcn_udot4(C, 0x37312212u, 0u, false), false);
+        const uint32_t a0 = __builtin_amdgcn_alignbyte(C, Lw, 1), b0 = __builtin_amdgcn_alignbyte(R, C, 1);
+        const uint32_t a1 = __builtin_amdgcn_alignbyte(C, Lw, 2), b1 = __builtin_amdgcn_alignbyte(R, C, 2);
+        const uint32_t a2 = __builtin_amdgcn_alignbyte(C, Lw, 3), b2 = __builtin_amdgcn_alignbyte(R, C, 3);
+        uint32_t wr[4];
+        wr[0] = __builtin_amdgcn_udot4(b0, 0x00122231u, __builtin_amdgcn_udot4(a0, 0x37312212u, 0u, false), false);
+        wr[1] = __builtin_amdgcn_udot4(b1, 0x00122231u, __builtin_amdgcn_udot4(a1, 0x37312212u, 0u, false), false);
+        wr[2] = __builtin_amdgcn_udot4(b2, 0x00122231u, __builtin_amdgcn_udot4(a2, 0x37312212u, 0u, false), false);
+        wr[3] = __builtin_amdgcn_udot4(R, 0x00122231u, __builtin_amdgcn_udot4(C, 0x37312212u, 0u, false), false);
         if (r >= 6) {
-            const int y = y0 + r - 6;  // wave-uniform
-            const uint32_t o = blur_col(wn, r, 0) | (blur_col(wn, r, 1) << 8) | (blur_col(wn, r, 2) << 16) |
-                               (blur_col(wn, r, 3) << 24);
-            if (y < h && store_ok) D[(uint64_t)y * ddw] = o;
+            const int y = y0 + r - 6;
+            const uint32_t o = blur_col(pr, wr[0], r, 0) | (blur_col(pr, wr[1], r, 1) << 8) |
+                               (blur_col(pr, wr[2], r, 2) << 16) | (blur_col(pr, wr[3], r, 3) << 24);
+            const int vs = (store_ok && y < h) ? y * dpitch + x0 : kOut;
+            __builtin_amdgcn_raw_buffer_store_b32(o, rd, vs, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (r >= 1) pr[(r + 5) % 6][k] = __builtin_amdgcn_perm(wr[k], wp[k], 0x05040100u);  // rows (r-1, r)
+            wp[k] = wr[k];
         }
     }
 }

@@ -249,6 +249,7 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
         D.size = (float)(int)(31 * c->tab.scale[l]);  // reference :930
         dense_off += g.max_cand;
         kp_off += g.max_kp;
+        B.blur_first[l + 1] = B.blur_first[l] + blur_main_blocks(g.w, g.h) + blur_edge_blocks(g.h);
     }
     hipStream_t st = c->stream;
     const bool prof = c->profiling;
@@ -272,12 +273,8 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
                        (const uint32_t*)c->d_ccount.p, (uint32_t*)c->d_dense_pts.p, (uint16_t*)c->d_dense_node.p,
                        (uint32_t*)c->d_lvl_kps.p, (int32_t*)c->d_lvl_count.p);
     if (prof) HIP_TRY(c, hipEventRecord(c->ev[3], st));
-    // stage 3: blur
-    for (int l = 0; l < L; ++l) {
-        const LevelDev& D = B.lv[l];
-        dim3 grid((D.w + 255) / 256 + 1, (D.h + 4 * kBlurRows - 1) / (4 * kBlurRows), n);
-        hipLaunchKernelGGL(k_blur7_stream, grid, dim3(64, 4), 0, st, D.img, D.pitch, D.plane, D.blur, D.bpitch, D.bplane, D.w, D.h);
-    }
+    // stage 3: blur, all levels in one launch
+    hipLaunchKernelGGL(k_blur7_all, dim3(B.blur_first[L], n), dim3(256), 0, st, B);
     if (prof) HIP_TRY(c, hipEventRecord(c->ev[4], st));
     // stage 4: orientation + descriptors + output assembly
     hipLaunchKernelGGL(k_orient_describe, dim3((c->max_kp_level + 3) / 4, L, n), dim3(256), 0, st, B,
