@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -212,6 +213,10 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     B.kp_total = c->kp_total;
     B.ini_th = c->prm.ini_th_fast;
     B.min_th = c->prm.min_th_fast;
+    {
+        const char* e = getenv("ORBX_DBG");
+        B.dbg = e ? atoi(e) : 0;
+    }
     size_t poff = 0, boff = 0;
     int dense_off = 0, kp_off = 0;
     const bool l0_in_arena = (l0 == nullptr);
