@@ -1,0 +1,167 @@
+// ORB_SLAM2::ORBextractor on top of the orbx C ABI (see include/ORBextractor.h).
+// Build with the host compiler against OpenCV and link with liborbx.so:
+//   g++ -std=c++11 -Iinclude $(pkg-config --cflags opencv) -c orb_slam2_amd/csrc/ORBextractor.cc
+#include "ORBextractor.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "orbx.h"
+
+namespace ORB_SLAM2 {
+
+namespace {
+const int EDGE_THRESHOLD = 19;  // reference src/ORBextractor.cc:75
+
+void Fatal(const char* what, int code, const orbx_ctx* ctx) {
+    std::fprintf(stderr, "ORBextractor (orbx): %s failed: %s (%d), hipError %d\n", what, orbx_strerror(code), code,
+                 ctx ? orbx_last_hip_error(ctx) : 0);
+    std::abort();
+}
+
+inline int Reflect101(int p, int len) {
+    if (p < 0) p = -p;
+    if (p >= len) p = 2 * len - 2 - p;
+    return p;
+}
+}  // namespace
+
+// Reference src/ORBextractor.cc:416-494.  The tables come from the library so that the host
+// getters and the device agree bit for bit.
+ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
+    : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST),
+      minThFAST(_minThFAST), mpCtx(NULL), mnCtxWidth(0), mnCtxHeight(0), mnDevice(0), mbKeepPyramid(true) {
+    mvScaleFactor.resize(nlevels);
+    mvInvScaleFactor.resize(nlevels);
+    mvLevelSigma2.resize(nlevels);
+    mvInvLevelSigma2.resize(nlevels);
+    mnFeaturesPerLevel.resize(nlevels);
+    umax.resize(16);
+    std::vector<int32_t> quota(nlevels), um(16);
+    int rc = orbx_host_tables(nfeatures, _scaleFactor, nlevels, &mvScaleFactor[0], &mvInvScaleFactor[0],
+                              &mvLevelSigma2[0], &mvInvLevelSigma2[0], &quota[0], &um[0]);
+    if (rc != ORBX_OK) Fatal("orbx_host_tables", rc, NULL);
+    for (int i = 0; i < nlevels; i++) mnFeaturesPerLevel[i] = quota[i];
+    for (int i = 0; i < 16; i++) umax[i] = um[i];
+    mvImagePyramid.resize(nlevels);
+    if (const char* e = std::getenv("ORBX_DEVICE")) mnDevice = std::atoi(e);
+    if (const char* e = std::getenv("ORBX_KEEP_PYRAMID")) mbKeepPyramid = std::atoi(e) != 0;
+}
+
+ORBextractor::~ORBextractor() {
+    if (mpCtx) orbx_destroy(mpCtx);
+}
+
+void ORBextractor::EnsureContext(int width, int height) {
+    if (mpCtx && width <= mnCtxWidth && height <= mnCtxHeight) return;
+    if (mpCtx) orbx_destroy(mpCtx);
+    mpCtx = NULL;
+    orbx_params p;
+    std::memset(&p, 0, sizeof(p));
+    p.nfeatures = nfeatures;
+    p.scale_factor = (float)scaleFactor;
+    p.nlevels = nlevels;
+    p.ini_th_fast = iniThFAST;
+    p.min_th_fast = minThFAST;
+    p.device_id = mnDevice;
+    p.max_width = width > mnCtxWidth ? width : mnCtxWidth;
+    p.max_height = height > mnCtxHeight ? height : mnCtxHeight;
+    p.max_batch = 1;
+    int rc = orbx_create(&p, &mpCtx);
+    if (rc != ORBX_OK) Fatal("orbx_create", rc, NULL);
+    mnCtxWidth = p.max_width;
+    mnCtxHeight = p.max_height;
+}
+
+// Reference src/ORBextractor.cc:1137-1211.
+void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint>& _keypoints,
+                              cv::OutputArray _descriptors) {
+    if (_image.empty()) return;
+    cv::Mat image = _image.getMat();
+    if (image.type() != CV_8UC1) {
+        std::fprintf(stderr, "ORBextractor (orbx): image must be CV_8UC1\n");  // the reference asserts (:1144)
+        std::abort();
+    }
+    EnsureContext(image.cols, image.rows);
+    const int cap = orbx_host_max_keypoints(nfeatures, (float)scaleFactor, nlevels, image.cols, image.rows);
+    if (cap < 0) Fatal("orbx_host_max_keypoints", cap, mpCtx);
+    std::vector<orbx_kp> kps(cap);
+    std::vector<unsigned char> desc((size_t)cap * 32);
+    int n = 0;
+    int rc = orbx_extract(mpCtx, image.data, image.cols, image.rows, (int)image.step, &kps[0], cap, &desc[0], &n);
+    if (rc != ORBX_OK) Fatal("orbx_extract", rc, mpCtx);
+
+    if (n == 0)
+        _descriptors.release();
+    else {
+        _descriptors.create(n, 32, CV_8U);
+        cv::Mat d = _descriptors.getMat();
+        for (int i = 0; i < n; i++) std::memcpy(d.ptr(i), &desc[(size_t)i * 32], 32);
+    }
+    _keypoints.clear();
+    _keypoints.reserve(n);
+    for (int i = 0; i < n; i++) {
+        cv::KeyPoint k;
+        k.pt.x = kps[i].x;
+        k.pt.y = kps[i].y;
+        k.size = kps[i].size;
+        k.angle = kps[i].angle;
+        k.response = kps[i].response;
+        k.octave = kps[i].octave;
+        k.class_id = kps[i].class_id;
+        _keypoints.push_back(k);
+    }
+
+    // mvImagePyramid as ComputePyramid leaves it (reference :1213-1250): each level is the ROI at
+    // (19,19) of a buffer carrying a 19-pixel reflect-101 border.
+    if (mbKeepPyramid) {
+        for (int level = 0; level < nlevels; ++level) {
+            orbx_level_geom g;
+            rc = orbx_host_level_geometry(nfeatures, (float)scaleFactor, nlevels, image.cols, image.rows, level, &g);
+            if (rc != ORBX_OK) Fatal("orbx_host_level_geometry", rc, mpCtx);
+            cv::Mat temp(g.height + 2 * EDGE_THRESHOLD, g.width + 2 * EDGE_THRESHOLD, CV_8UC1);
+            cv::Mat roi = temp(cv::Rect(EDGE_THRESHOLD, EDGE_THRESHOLD, g.width, g.height));
+            int w = 0, h = 0;
+            rc = orbx_pyramid_level(mpCtx, 0, level, roi.data, (int)roi.step, &w, &h);
+            if (rc != ORBX_OK) Fatal("orbx_pyramid_level", rc, mpCtx);
+            for (int y = -EDGE_THRESHOLD; y < h + EDGE_THRESHOLD; y++) {
+                unsigned char* drow = temp.ptr(y + EDGE_THRESHOLD);
+                const unsigned char* srow = roi.ptr(Reflect101(y, h));
+                if (y < 0 || y >= h) std::memcpy(drow + EDGE_THRESHOLD, srow, w);
+                for (int x = 1; x <= EDGE_THRESHOLD; x++) {
+                    drow[EDGE_THRESHOLD - x] = srow[Reflect101(-x, w)];
+                    drow[EDGE_THRESHOLD + w - 1 + x] = srow[Reflect101(w - 1 + x, w)];
+                }
+            }
+            mvImagePyramid[level] = roi;
+        }
+    }
+}
+
+// Source compatibility only (reference src/ORBextractor.cc:507-570): splits the node's box at the
+// ceil-halved midpoints and deals its keys to the four quadrants.
+void ExtractorNode::DivideNode(ExtractorNode& n1, ExtractorNode& n2, ExtractorNode& n3, ExtractorNode& n4) {
+    const int mx = UL.x + (int)std::ceil((float)(UR.x - UL.x) / 2);
+    const int my = UL.y + (int)std::ceil((float)(BR.y - UL.y) / 2);
+    ExtractorNode* child[4] = {&n1, &n2, &n3, &n4};
+    for (int q = 0; q < 4; q++) {
+        const int x0 = (q & 1) ? mx : UL.x, x1 = (q & 1) ? UR.x : mx;
+        const int y0 = (q & 2) ? my : UL.y, y1 = (q & 2) ? BL.y : my;
+        child[q]->UL = cv::Point2i(x0, y0);
+        child[q]->UR = cv::Point2i(x1, y0);
+        child[q]->BL = cv::Point2i(x0, y1);
+        child[q]->BR = cv::Point2i(x1, y1);
+        child[q]->vKeys.reserve(vKeys.size());
+    }
+    for (size_t i = 0; i < vKeys.size(); i++) {
+        const cv::KeyPoint& kp = vKeys[i];
+        const int q = (kp.pt.x < mx ? 0 : 1) + (kp.pt.y < my ? 0 : 2);
+        child[q]->vKeys.push_back(kp);
+    }
+    for (int q = 0; q < 4; q++)
+        if (child[q]->vKeys.size() == 1) child[q]->bNoMore = true;
+}
+
+}  // namespace ORB_SLAM2

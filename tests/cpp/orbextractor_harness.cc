@@ -1,0 +1,61 @@
+// Test harness for the drop-in C++ class (include/ORBextractor.h).
+//   harness tables <nfeatures> <scale> <nlevels>                 -> prints the getter tables
+//   harness extract <nf> <scale> <nl> <ini> <min> <w> <h> <stride> <in.raw> <out.bin>
+// out.bin: int32 K, K*28 bytes keypoints (cv::KeyPoint field order), K*32 bytes descriptors,
+// then per level: int32 w, int32 h, (w+38)*(h+38) bytes of the padded pyramid buffer.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "ORBextractor.h"
+
+int main(int argc, char** argv) {
+    if (argc >= 5 && !std::strcmp(argv[1], "tables")) {
+        ORB_SLAM2::ORBextractor ex(std::atoi(argv[2]), (float)std::atof(argv[3]), std::atoi(argv[4]), 20, 7);
+        std::printf("levels %d scale %.9g\n", ex.GetLevels(), ex.GetScaleFactor());
+        std::vector<float> a = ex.GetScaleFactors(), b = ex.GetInverseScaleFactors(), c = ex.GetScaleSigmaSquares(),
+                           d = ex.GetInverseScaleSigmaSquares();
+        for (size_t i = 0; i < a.size(); i++) std::printf("%.9g %.9g %.9g %.9g\n", a[i], b[i], c[i], d[i]);
+        return 0;
+    }
+    if (argc >= 12 && !std::strcmp(argv[1], "extract")) {
+        const int nf = std::atoi(argv[2]), nl = std::atoi(argv[4]), ini = std::atoi(argv[5]), mn = std::atoi(argv[6]);
+        const float sc = (float)std::atof(argv[3]);
+        const int w = std::atoi(argv[7]), h = std::atoi(argv[8]), stride = std::atoi(argv[9]);
+        std::vector<unsigned char> raw((size_t)stride * h);
+        FILE* f = std::fopen(argv[10], "rb");
+        if (!f || std::fread(&raw[0], 1, raw.size(), f) != raw.size()) return 2;
+        std::fclose(f);
+        cv::Mat img(h, w, CV_8UC1, &raw[0], (size_t)stride);
+        ORB_SLAM2::ORBextractor ex(nf, sc, nl, ini, mn);
+        std::vector<cv::KeyPoint> kps;
+        cv::Mat desc;
+        ex(cv::Mat(), cv::Mat(), kps, desc);  // empty image: outputs untouched
+        if (!kps.empty() || !desc.empty()) return 3;
+        ex(img, cv::Mat(), kps, desc);
+        ex(img, cv::Mat(), kps, desc);  // second call on the same context
+        FILE* o = std::fopen(argv[11], "wb");
+        if (!o) return 4;
+        int K = (int)kps.size();
+        std::fwrite(&K, 4, 1, o);
+        for (int i = 0; i < K; i++) {
+            float v[5] = {kps[i].pt.x, kps[i].pt.y, kps[i].size, kps[i].angle, kps[i].response};
+            int q[2] = {kps[i].octave, kps[i].class_id};
+            std::fwrite(v, 4, 5, o);
+            std::fwrite(q, 4, 2, o);
+        }
+        for (int i = 0; i < K; i++) std::fwrite(desc.ptr(i), 1, 32, o);
+        for (int l = 0; l < nl; l++) {
+            const cv::Mat& roi = ex.mvImagePyramid[l];
+            int dims[2] = {roi.cols, roi.rows};
+            std::fwrite(dims, 4, 2, o);
+            const unsigned char* base = roi.data - 19 * roi.step - 19;
+            for (int y = 0; y < roi.rows + 38; y++) std::fwrite(base + (size_t)y * roi.step, 1, roi.cols + 38, o);
+        }
+        std::fclose(o);
+        return 0;
+    }
+    std::fprintf(stderr, "usage: see source\n");
+    return 1;
+}
