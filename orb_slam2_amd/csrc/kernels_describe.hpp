@@ -62,27 +62,36 @@ __device__ __forceinline__ void sincos_pinned(float angf, float* c_out, float* s
 
 constexpr int kIcCount = 749;  // pixels of the radius-15 disc
 
-// grid = (ceil(max level keypoints / 4), nlevels, frames), block = 256 (one wave per keypoint).
+// grid = 8 * ceil(frames/8) * nlevels * kp_blocks (1-D), block = 256 (one wave per keypoint).
+// Workgroups are dealt round-robin to the 8 XCDs, so block ids are decoded as
+// (id % 8, id / 8) = (XCD lane, work index) and every frame is given to one XCD lane: all
+// keypoints of a frame then gather from the same L2 instead of pulling the frame's pyramid into
+// eight of them.  This is a locality hint only; correctness does not depend on placement.
 __global__ __launch_bounds__(256) void k_orient_describe(BatchDev B, const uint32_t* __restrict__ lvl_kps,
                                                          const int32_t* __restrict__ lvl_count,
                                                          const int8_t* __restrict__ ic_uv,   // 749 (u, v) pairs
                                                          const int8_t* __restrict__ pattern, // 512 (x, y) pairs
                                                          orbx_kp* __restrict__ out_kps, uint8_t* __restrict__ out_desc,
-                                                         int32_t* __restrict__ out_n, int kp_cap) {
+                                                         int32_t* __restrict__ out_n, int kp_cap, int kp_blocks) {
     __shared__ int8_t s_pat[1024];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int level = blockIdx.y, frame = blockIdx.z;
+    const int per_frame = B.nlevels * kp_blocks;
+    const int xl = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int frame = (j / per_frame) * 8 + xl;
+    if (frame >= B.nframes) return;
+    const int rem = j % per_frame;
+    const int level = rem / kp_blocks, kblk = rem % kp_blocks;
     const int32_t* counts = lvl_count + (uint64_t)frame * B.nlevels;
     const int n = counts[level];
-    if (blockIdx.x == 0 && level == 0 && tid == 0) {
+    if (kblk == 0 && level == 0 && tid == 0) {
         int tot = 0;
         for (int l = 0; l < B.nlevels; ++l) tot += counts[l];
         out_n[frame] = min(tot, kp_cap);
     }
-    if (blockIdx.x * 4 >= n) return;  // whole block idle (uniform)
+    if (kblk * 4 >= n) return;  // whole block idle (uniform)
     reinterpret_cast<uint32_t*>(s_pat)[tid] = reinterpret_cast<const uint32_t*>(pattern)[tid];
     __syncthreads();
-    const int i = blockIdx.x * 4 + wave;
+    const int i = kblk * 4 + wave;
     if (i >= n) return;
     const LevelDev& L = B.lv[level];
     int base = 0;
@@ -96,11 +105,21 @@ __global__ __launch_bounds__(256) void k_orient_describe(BatchDev B, const uint3
     // intensity centroid over the disc, on the un-blurred level
     const uint8_t* c = L.img + (uint64_t)frame * L.plane + (uint64_t)y * L.pitch + x;
     int m10 = 0, m01 = 0;
-    for (int j = lane; j < kIcCount; j += 64) {
-        const int u = ic_uv[2 * j], v = ic_uv[2 * j + 1];
-        const int val = c[v * L.pitch + u];
-        m10 += u * val;
-        m01 += v * val;
+    int uu[12], vv[12], val[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {  // 749 = 11*64 + 45: all loads issued before the first use
+        const int jj = min(lane + 64 * t, kIcCount - 1);
+        const int16_t uv = reinterpret_cast<const int16_t*>(ic_uv)[jj];
+        uu[t] = (int8_t)(uv & 0xFF);
+        vv[t] = (int8_t)(uv >> 8);
+    }
+#pragma unroll
+    for (int t = 0; t < 12; ++t) val[t] = c[vv[t] * L.pitch + uu[t]];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {
+        const int ok = (lane + 64 * t) < kIcCount ? 1 : 0;
+        m10 += ok * uu[t] * val[t];
+        m01 += ok * vv[t] * val[t];
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {

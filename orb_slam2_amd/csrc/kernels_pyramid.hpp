@@ -10,37 +10,92 @@ namespace orbx {
 // cv::resize(level l-1 -> level l, INTER_LINEAR), 8UC1 fixed-point path of OpenCV 3.4.5:
 //   T(dx)  = S[sx]*a0 + S[sx+1]*a1                      (11-bit weights, int32)
 //   D      = (((b0*(T0>>4))>>16) + ((b1*(T1>>4))>>16) + 2) >> 2
-// One thread produces four horizontally adjacent destination pixels and stores one dword.
-// grid = (ceil(dw/256), ceil(dh/4), frames), block = (64, 4).
+// A workgroup produces a 256 x 16 destination tile.  The source rows and columns the tile's taps
+// touch are staged in LDS with 16-byte loads (one vector-memory instruction moves 1 KiB), the tap
+// tables of the tile's columns and rows go to LDS as well, and the per-pixel gathers
+// (S[sx], S[sx+1] of two rows) are LDS byte reads.  A thread produces four horizontally adjacent
+// destination pixels of four rows and stores one dword per row.
+// grid = (ceil(dw/256), ceil(dh/16), frames), block = 256,
+// dynamic LDS = resize_lds_bytes(...) (source tile + 256 column taps + 16 row taps).
+constexpr int kRsTW = 256, kRsTH = 16;
+
+__host__ __device__ inline int resize_src_pitch(int max_col_span) { return ((max_col_span + 15 + 16) & ~15); }
+
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, int spitch, uint64_t splane,
-                                                uint8_t* __restrict__ dst, int dpitch, uint64_t dplane,
-                                                int dw, int dh, const ResizeTap* __restrict__ xt,
-                                                const ResizeTap* __restrict__ yt) {
-    const int dy = blockIdx.y * 4 + threadIdx.y;
-    const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    if (dy >= dh || dx0 >= dw) return;
-    const ResizeTap ty = yt[dy];
-    const uint8_t* r0 = src + (uint64_t)blockIdx.z * splane + (uint64_t)ty.ofs * spitch;
-    const uint8_t* r1 = src + (uint64_t)blockIdx.z * splane + (uint64_t)ty.ofs1 * spitch;
-    const int b0 = ty.c0, b1 = ty.c1;
-    uint32_t out = 0;
-    const int nvalid = min(4, dw - dx0);
+                                                int sw, int sh, uint8_t* __restrict__ dst, int dpitch,
+                                                uint64_t dplane, int dw, int dh, const ResizeTap* __restrict__ xt,
+                                                const ResizeTap* __restrict__ yt, int lds_pitch, int lds_rows) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_rs[];
+    uint8_t* s_src = s_rs;
+    ResizeTap* s_xt = reinterpret_cast<ResizeTap*>(s_rs + lds_pitch * lds_rows);
+    ResizeTap* s_yt = s_xt + kRsTW;
+    const int tid = threadIdx.x;
+    const int dx_first = blockIdx.x * kRsTW, dy_first = blockIdx.y * kRsTH;
+    const int ncol = min(kRsTW, dw - dx_first), nrow = min(kRsTH, dh - dy_first);
+    // source window of the tile: taps are monotone in the destination index
+    const int c_lo = xt[dx_first].ofs & ~15, c_hi = xt[dx_first + ncol - 1].ofs1;
+    const int r_lo = yt[dy_first].ofs, r_hi = yt[dy_first + nrow - 1].ofs1;
+    const int nchunk = ((c_hi - c_lo) >> 4) + 1, nr = r_hi - r_lo + 1;
+    const uint8_t* S = src + (uint64_t)blockIdx.z * splane;
+    const bool wide = ((spitch & 15) == 0) && ((reinterpret_cast<uintptr_t>(S) & 15) == 0);
+    const float inv_chunk = 1.0f / (float)nchunk;
+    if (wide) {
+        for (int i = tid; i < nr * nchunk; i += 256) {
+            const int r = (int)(((float)i + 0.5f) * inv_chunk), c = i - r * nchunk;
+            const uint4 v = *reinterpret_cast<const uint4*>(S + (uint64_t)(r_lo + r) * spitch + c_lo + 16 * c);
+            *reinterpret_cast<uint4*>(s_src + r * lds_pitch + 16 * c) = v;
+        }
+    } else {
+        // rows are only 4-byte aligned (a caller's level-0 buffer used in place)
+        for (int i = tid; i < nr * nchunk * 4; i += 256) {
+            const int r = (int)(((float)i + 0.5f) * inv_chunk * 0.25f), c = i - r * nchunk * 4;
+            const int col = min(c_lo + 4 * c, spitch - 4);
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(S + (uint64_t)(r_lo + r) * spitch + col);
+            *reinterpret_cast<uint32_t*>(s_src + r * lds_pitch + 4 * c) = v;
+        }
+    }
+    if (tid < ncol) {
+        ResizeTap t = xt[dx_first + tid];
+        t.ofs = (int16_t)(t.ofs - c_lo);
+        t.ofs1 = (int16_t)(t.ofs1 - c_lo);
+        s_xt[tid] = t;
+    }
+    if (tid < nrow) {
+        ResizeTap t = yt[dy_first + tid];
+        t.ofs = (int16_t)((t.ofs - r_lo) * lds_pitch);
+        t.ofs1 = (int16_t)((t.ofs1 - r_lo) * lds_pitch);
+        s_yt[tid] = t;
+    }
+    __syncthreads();
+    const int lx = (tid & 63) * 4;
+    if (lx >= ncol) return;
+    const int nvalid = min(4, ncol - lx);
+    ResizeTap tx[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (k < nvalid) {
-            const ResizeTap tx = xt[dx0 + k];
-            const int t0 = r0[tx.ofs] * tx.c0 + r0[tx.ofs1] * tx.c1;
-            const int t1 = r1[tx.ofs] * tx.c0 + r1[tx.ofs1] * tx.c1;
-            int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+    for (int k = 0; k < 4; ++k) tx[k] = s_xt[min(lx + k, ncol - 1)];
+    uint8_t* D = dst + (uint64_t)blockIdx.z * dplane + dx_first + lx;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int ly = (tid >> 6) + 4 * rr;
+        if (ly >= nrow) break;
+        const ResizeTap ty = s_yt[ly];
+        const uint8_t* r0 = s_src + ty.ofs;
+        const uint8_t* r1 = s_src + ty.ofs1;
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t0 = (int)__umul24(r0[tx[k].ofs], tx[k].c0) + (int)__umul24(r0[tx[k].ofs1], tx[k].c1);
+            const int t1 = (int)__umul24(r1[tx[k].ofs], tx[k].c0) + (int)__umul24(r1[tx[k].ofs1], tx[k].c1);
+            int v = (((ty.c0 * (t0 >> 4)) >> 16) + ((ty.c1 * (t1 >> 4)) >> 16) + 2) >> 2;
             v = min(max(v, 0), 255);
             out |= (uint32_t)v << (8 * k);
         }
-    }
-    uint8_t* d = dst + (uint64_t)blockIdx.z * dplane + (uint64_t)dy * dpitch + dx0;
-    if (nvalid == 4) {
-        *reinterpret_cast<uint32_t*>(d) = out;
-    } else {
-        for (int k = 0; k < nvalid; ++k) d[k] = (uint8_t)(out >> (8 * k));
+        uint8_t* d = D + (uint64_t)(dy_first + ly) * dpitch;
+        if (nvalid == 4) {
+            *reinterpret_cast<uint32_t*>(d) = out;
+        } else {
+            for (int k = 0; k < nvalid; ++k) d[k] = (uint8_t)(out >> (8 * k));
+        }
     }
 }
 

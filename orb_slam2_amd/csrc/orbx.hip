@@ -44,6 +44,7 @@ struct orbx_ctx {
     std::vector<LevelGeom> levels;
     std::vector<CellDesc> cells;
     std::vector<TileDesc> tiles;
+    int rs_pitch[ORBX_MAX_LEVELS], rs_rows[ORBX_MAX_LEVELS];  // resize source tile in LDS
     int fast_tile_bytes = 0, fast_plane_bytes = 0;
     size_t fast_lds = 0;
     int pitch[ORBX_MAX_LEVELS];
@@ -152,6 +153,22 @@ int set_geometry(orbx_ctx* c, int w, int h) {
         std::vector<ResizeTap> xt, yt;
         build_resize_taps(levels[l - 1].w, levels[l].w, true, &xt);
         build_resize_taps(levels[l - 1].h, levels[l].h, false, &yt);
+        {
+            // largest source window of a 256 x 16 destination tile
+            int span_c = 0, span_r = 0;
+            for (size_t d0 = 0; d0 < xt.size(); d0 += kRsTW) {
+                const size_t d1 = std::min(xt.size(), d0 + kRsTW) - 1;
+                span_c = std::max(span_c, xt[d1].ofs1 - (xt[d0].ofs & ~15) + 1);
+            }
+            for (size_t d0 = 0; d0 < yt.size(); d0 += kRsTH) {
+                const size_t d1 = std::min(yt.size(), d0 + kRsTH) - 1;
+                span_r = std::max(span_r, yt[d1].ofs1 - yt[d0].ofs + 1);
+            }
+            c->rs_pitch[l] = resize_src_pitch(span_c);
+            c->rs_rows[l] = span_r;
+            const size_t need = (size_t)c->rs_pitch[l] * span_r + (kRsTW + kRsTH) * sizeof(ResizeTap);
+            if (need > 60 * 1024 || (size_t)c->rs_pitch[l] * span_r > 32767) return ORBX_E_GEOMETRY;  // scale factor too large
+        }
         rc = ensure(c, &c->d_xt[l], xt.size() * sizeof(ResizeTap));
         if (rc) return rc;
         rc = ensure(c, &c->d_yt[l], yt.size() * sizeof(ResizeTap));
@@ -263,9 +280,11 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     for (int l = 1; l < L; ++l) {
         const LevelDev& S = B.lv[l - 1];
         const LevelDev& D = B.lv[l];
-        dim3 grid((D.w + 255) / 256, (D.h + 3) / 4, n), block(64, 4);
-        hipLaunchKernelGGL(k_resize, grid, block, 0, st, S.img, S.pitch, S.plane, const_cast<uint8_t*>(D.img), D.pitch,
-                           D.plane, D.w, D.h, (const ResizeTap*)c->d_xt[l].p, (const ResizeTap*)c->d_yt[l].p);
+        dim3 grid((D.w + kRsTW - 1) / kRsTW, (D.h + kRsTH - 1) / kRsTH, n);
+        const size_t lds = (size_t)c->rs_pitch[l] * c->rs_rows[l] + (kRsTW + kRsTH) * sizeof(ResizeTap);
+        hipLaunchKernelGGL(k_resize, grid, dim3(256), lds, st, S.img, S.pitch, S.plane, S.w, S.h,
+                           const_cast<uint8_t*>(D.img), D.pitch, D.plane, D.w, D.h, (const ResizeTap*)c->d_xt[l].p,
+                           (const ResizeTap*)c->d_yt[l].p, c->rs_pitch[l], c->rs_rows[l]);
     }
     if (prof) HIP_TRY(c, hipEventRecord(c->ev[1], st));
     // stage 1: FAST cells
@@ -282,9 +301,13 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     hipLaunchKernelGGL(k_blur7_all, dim3(B.blur_first[L], n), dim3(256), 0, st, B);
     if (prof) HIP_TRY(c, hipEventRecord(c->ev[4], st));
     // stage 4: orientation + descriptors + output assembly
-    hipLaunchKernelGGL(k_orient_describe, dim3((c->max_kp_level + 3) / 4, L, n), dim3(256), 0, st, B,
-                       (const uint32_t*)c->d_lvl_kps.p, (const int32_t*)c->d_lvl_count.p, (const int8_t*)c->d_ic.p,
-                       (const int8_t*)c->d_pat.p, d_kps, d_desc, d_n_out, kp_cap);
+    {
+        const int kp_blocks = (c->max_kp_level + 3) / 4;
+        const unsigned grid = 8u * (unsigned)((n + 7) / 8) * (unsigned)L * (unsigned)kp_blocks;
+        hipLaunchKernelGGL(k_orient_describe, dim3(grid), dim3(256), 0, st, B, (const uint32_t*)c->d_lvl_kps.p,
+                           (const int32_t*)c->d_lvl_count.p, (const int8_t*)c->d_ic.p, (const int8_t*)c->d_pat.p,
+                           d_kps, d_desc, d_n_out, kp_cap, kp_blocks);
+    }
     if (prof) {
         HIP_TRY(c, hipEventRecord(c->ev[5], st));
         c->ev_valid = true;
