@@ -126,7 +126,7 @@ int set_geometry(orbx_ctx* c, int w, int h) {
     build_fast_tiles(levels, cells, &tiles);
     int tile_b = 0, plane_b = 0, queue_b = 0;
     for (const TileDesc& t : tiles) {
-        const FastLds need = fast_lds_need(t.x_first, t.wd, t.hd, t.nc);
+        const FastLds need = fast_lds_need(t.wd, t.hd, t.nc);
         tile_b = std::max(tile_b, need.tile);
         plane_b = std::max(plane_b, need.plane);
         queue_b = std::max(queue_b, need.queue);
