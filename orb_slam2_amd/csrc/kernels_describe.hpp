@@ -60,20 +60,46 @@ __device__ __forceinline__ void sincos_pinned(float angf, float* c_out, float* s
     *s_out = (float)ss;
 }
 
-constexpr int kIcCount = 749;  // pixels of the radius-15 disc
+constexpr int kPatchRows = 37, kPatchDw = 10, kPatchPitch = 40;  // blurred neighbourhood of a keypoint in LDS
+constexpr int kPatchLoads = (kPatchRows * kPatchDw + 63) / 64;      // dwords per lane
+constexpr int kDescPerWave = 8;              // keypoints a wave handles in turn
+constexpr int kDescKp = 4 * kDescPerWave;    // keypoints per workgroup
 
-// grid = 8 * ceil(frames/8) * nlevels * kp_blocks (1-D), block = 256 (one wave per keypoint).
+// Wave-wide integer sum through DPP (no LDS traffic); the total lands in lane 63.
+__device__ __forceinline__ int wave_sum_to_lane63(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);  // row_mirror: every lane holds its row's sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+typedef uint32_t desc_u32_unaligned __attribute__((aligned(1)));
+
+// One workgroup handles up to kDescKp retained keypoints of one (frame, level) in three phases:
+//  A. orientation moments: each wave takes its keypoints in turn; the 31x31 patch is read as 31
+//     rows of 8 (unaligned) dwords, 4 dwords per lane, and v_dot4_u32_u8 against per-lane constant
+//     weight dwords (u+16 inside the disc, 0 outside; 1 inside, 0 outside) yields
+//     m10 = sum(u*I) and m01 = sum(v*I) exactly; a DPP reduction leaves the sums in LDS;
+//  B. one thread per keypoint evaluates fastAtan2, the pinned sin/cos, and writes the 28-byte
+//     keypoint record (so the double-precision work is done once per keypoint, not per lane);
+//  C. each wave takes its keypoints again; lane l evaluates tests 4l..4l+3 (their eight
+//     pattern points are lane constants held in registers) on the blurred level.
 // Workgroups are dealt round-robin to the 8 XCDs, so block ids are decoded as
 // (id % 8, id / 8) = (XCD lane, work index) and every frame is given to one XCD lane: all
-// keypoints of a frame then gather from the same L2 instead of pulling the frame's pyramid into
-// eight of them.  This is a locality hint only; correctness does not depend on placement.
+// keypoints of a frame then gather from the same L2.  A locality hint only.
+// grid = 8 * ceil(frames/8) * nlevels * kp_blocks (1-D), block = 256.
 __global__ __launch_bounds__(256) void k_orient_describe(BatchDev B, const uint32_t* __restrict__ lvl_kps,
                                                          const int32_t* __restrict__ lvl_count,
-                                                         const int8_t* __restrict__ ic_uv,   // 749 (u, v) pairs
                                                          const int8_t* __restrict__ pattern, // 512 (x, y) pairs
                                                          orbx_kp* __restrict__ out_kps, uint8_t* __restrict__ out_desc,
                                                          int32_t* __restrict__ out_n, int kp_cap, int kp_blocks) {
-    __shared__ int8_t s_pat[1024];
+    __shared__ uint32_t s_pk[kDescKp];
+    __shared__ int s_m10[kDescKp], s_m01[kDescKp];
+    __shared__ float s_a[kDescKp], s_b[kDescKp];
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kPatchRows * kPatchPitch];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per_frame = B.nlevels * kp_blocks;
     const int xl = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -88,80 +114,170 @@ __global__ __launch_bounds__(256) void k_orient_describe(BatchDev B, const uint3
         for (int l = 0; l < B.nlevels; ++l) tot += counts[l];
         out_n[frame] = min(tot, kp_cap);
     }
-    if (kblk * 4 >= n) return;  // whole block idle (uniform)
-    reinterpret_cast<uint32_t*>(s_pat)[tid] = reinterpret_cast<const uint32_t*>(pattern)[tid];
-    __syncthreads();
-    const int i = kblk * 4 + wave;
-    if (i >= n) return;
+    const int first = kblk * kDescKp;
+    if (first >= n) return;  // whole block idle (uniform)
+    const int nk = min(kDescKp, n - first);
     const LevelDev& L = B.lv[level];
-    int base = 0;
-    for (int l = 0; l < level; ++l) base += counts[l];
-    const int o = base + i;
-    if (o >= kp_cap) return;
+    int base_out = 0;
+    for (int l = 0; l < level; ++l) base_out += counts[l];
+    base_out += first;
+    if (tid < nk) s_pk[tid] = lvl_kps[(uint64_t)frame * B.kp_total + L.kp_off + first + tid];
 
-    const uint32_t pk = lvl_kps[(uint64_t)frame * B.kp_total + L.kp_off + i];
-    const int x = pt_x(pk) + kBorder, y = pt_y(pk) + kBorder;  // level coordinates (:936-937)
-
-    // intensity centroid over the disc, on the un-blurred level
-    const uint8_t* c = L.img + (uint64_t)frame * L.plane + (uint64_t)y * L.pitch + x;
-    int m10 = 0, m01 = 0;
-    int uu[12], vv[12], val[12];
-#pragma unroll
-    for (int t = 0; t < 12; ++t) {  // 749 = 11*64 + 45: all loads issued before the first use
-        const int jj = min(lane + 64 * t, kIcCount - 1);
-        const int16_t uv = reinterpret_cast<const int16_t*>(ic_uv)[jj];
-        uu[t] = (int8_t)(uv & 0xFF);
-        vv[t] = (int8_t)(uv >> 8);
-    }
-#pragma unroll
-    for (int t = 0; t < 12; ++t) val[t] = c[vv[t] * L.pitch + uu[t]];
-#pragma unroll
-    for (int t = 0; t < 12; ++t) {
-        const int ok = (lane + 64 * t) < kIcCount ? 1 : 0;
-        m10 += ok * uu[t] * val[t];
-        m01 += ok * vv[t] * val[t];
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        m10 += __shfl_xor(m10, d);
-        m01 += __shfl_xor(m01, d);
-    }
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
-
-    // rotated BRIEF tests on the blurred level; lane handles tests 4*lane .. 4*lane+3
-    const float factor_pi = (float)(3.1415926535897932384626433832795 / 180.f);
-    float a, b;
-    sincos_pinned(__fmul_rn(angle, factor_pi), &a, &b);
-    const uint8_t* cb = L.blur + (uint64_t)frame * L.bplane + (uint64_t)y * L.bpitch + x;
-    uint32_t bits = 0;
+    // ---- lane constants of phase A: four patch dwords (row, dword-of-row) and their weights ----
+    // Row half-widths of the radius-15 disc (reference src/ORBextractor.cc:473-493).
+    const int umax_tab[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    int ic_off[4], ic_v[4];
+    uint32_t ic_wu[4], ic_w1[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const int8_t* pp = &s_pat[(4 * lane + t) * 4];
-        int val[2];
+        const int it = lane + 64 * t;         // 0..255, 248 used
+        const int row = it >> 3, dwi = it & 7; // row 0..30 -> v = row-15; dword 0..7 -> u = 4*dwi-15 .. +3
+        const int vv = row - 15;
+        uint32_t wu = 0, w1 = 0;
+        if (row < 31) {
+            int um = 0;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float px = (float)pp[2 * e], py = (float)pp[2 * e + 1];
-            // the reference's -march=native build contracts x*b + y*a and x*a - y*b into one fma
-            const int row = (int)rintf(__fmaf_rn(px, b, __fmul_rn(py, a)));
-            const int col = (int)rintf(__fmaf_rn(px, a, -__fmul_rn(py, b)));
-            val[e] = cb[row * L.bpitch + col];
+            for (int q = 0; q < 16; ++q) um = (abs(vv) == q) ? umax_tab[q] : um;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const int u = 4 * dwi - 15 + bb;
+                if (abs(u) <= um) {
+                    wu |= (uint32_t)(u + 16) << (8 * bb);
+                    w1 |= 1u << (8 * bb);
+                }
+            }
         }
-        bits |= (val[0] < val[1] ? 1u : 0u) << t;
+        ic_wu[t] = wu;
+        ic_w1[t] = w1;
+        ic_v[t] = row < 31 ? vv : 0;
+        ic_off[t] = row < 31 ? vv * L.pitch + 4 * dwi - 15 : 0;
     }
-    const uint32_t other = __shfl_xor(bits, 1);
-    uint8_t* dsc = out_desc + ((uint64_t)frame * kp_cap + o) * 32;
-    if ((lane & 1) == 0) dsc[lane >> 1] = (uint8_t)(bits | (other << 4));
-    if (lane == 0) {
-        orbx_kp k;
-        const float fx = (float)x, fy = (float)y;
-        k.x = level ? __fmul_rn(fx, L.scale) : fx;  // :1198-1207
-        k.y = level ? __fmul_rn(fy, L.scale) : fy;
-        k.size = L.size;
-        k.angle = angle;
-        k.response = (float)pt_score(pk);
-        k.octave = level;
-        k.class_id = -1;
-        out_kps[(uint64_t)frame * kp_cap + o] = k;
+    // ---- lane constants of phase C: the eight pattern points of tests 4*lane .. 4*lane+3 ----
+    float pat_x[8], pat_y[8];
+    {
+        const int8_t* pp = pattern + 16 * lane;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            pat_x[e] = (float)pp[2 * e];
+            pat_y[e] = (float)pp[2 * e + 1];
+        }
+    }
+    __syncthreads();
+
+    // ---- A. orientation moments (the next keypoint's patch is in flight while this one is reduced) ----
+    const uint8_t* img = L.img + (uint64_t)frame * L.plane;
+    const int kp0 = wave * kDescPerWave;
+    const int cnt = max(0, min(kDescPerWave, nk - kp0));  // wave-uniform
+    auto patch_ptr = [&](int kp) {
+        const uint32_t pk = __builtin_amdgcn_readfirstlane(s_pk[kp]);
+        return img + (uint64_t)(pt_y(pk) + kBorder) * L.pitch + (pt_x(pk) + kBorder);  // level coordinates (:936-937)
+    };
+    uint32_t nx[4];
+    if (cnt > 0) {
+        const uint8_t* c = patch_ptr(kp0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) nx[t] = *reinterpret_cast<const desc_u32_unaligned*>(c + ic_off[t]);
+    }
+    for (int q = 0; q < cnt; ++q) {
+        uint32_t px[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) px[t] = nx[t];
+        if (q + 1 < cnt) {
+            const uint8_t* c = patch_ptr(kp0 + q + 1);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) nx[t] = *reinterpret_cast<const desc_u32_unaligned*>(c + ic_off[t]);
+        }
+        int m10 = 0, m01 = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int s1 = (int)__builtin_amdgcn_udot4(px[t], ic_w1[t], 0u, false);
+            const int su = (int)__builtin_amdgcn_udot4(px[t], ic_wu[t], 0u, false);
+            m10 += su - 16 * s1;
+            m01 += ic_v[t] * s1;
+        }
+        m10 = wave_sum_to_lane63(m10);
+        m01 = wave_sum_to_lane63(m01);
+        if (lane == 63) {
+            s_m10[kp0 + q] = m10;
+            s_m01[kp0 + q] = m01;
+        }
+    }
+    __syncthreads();
+
+    // ---- B. angle, rotation, keypoint record: one thread per keypoint ----
+    if (tid < nk) {
+        const uint32_t pk = s_pk[tid];
+        const float angle = fast_atan2_deg((float)s_m01[tid], (float)s_m10[tid]);
+        const float factor_pi = (float)(3.1415926535897932384626433832795 / 180.f);
+        float a, b;
+        sincos_pinned(__fmul_rn(angle, factor_pi), &a, &b);
+        s_a[tid] = a;
+        s_b[tid] = b;
+        const int o = base_out + tid;
+        if (o < kp_cap) {
+            orbx_kp k;
+            const float fx = (float)(pt_x(pk) + kBorder), fy = (float)(pt_y(pk) + kBorder);
+            k.x = level ? __fmul_rn(fx, L.scale) : fx;  // :1198-1207
+            k.y = level ? __fmul_rn(fy, L.scale) : fy;
+            k.size = L.size;
+            k.angle = angle;
+            k.response = (float)pt_score(pk);
+            k.octave = level;
+            k.class_id = -1;
+            out_kps[(uint64_t)frame * kp_cap + o] = k;
+        }
+    }
+    __syncthreads();
+
+    // ---- C. rotated BRIEF tests on the blurred level ----
+    // The 37x37 neighbourhood the rotated pattern can reach (|coordinate| <= 18) is copied to LDS
+    // with coalesced row loads (37 rows x 10 dwords, 6 per lane, the next keypoint's rows in flight
+    // while this one is evaluated); the 512 scattered samples are then LDS byte reads, so the
+    // vector cache sees each patch line once instead of once per gather instruction.
+    const uint8_t* blur = L.blur + (uint64_t)frame * L.bplane;
+    const int bp = L.bpitch;
+    uint8_t* my_patch = s_patch[wave];
+    int pr_off[kPatchLoads], pr_lds[kPatchLoads];
+#pragma unroll
+    for (int t = 0; t < kPatchLoads; ++t) {
+        const int it = min(lane + 64 * t, kPatchRows * kPatchDw - 1);
+        const int r = (int)(((float)it + 0.5f) * (1.0f / (float)kPatchDw)), k = it - r * kPatchDw;
+        pr_off[t] = (r - 18) * bp + 4 * k - 18;
+        pr_lds[t] = r * kPatchPitch + 4 * k;
+    }
+    auto fetch = [&](int kp, uint32_t (&reg)[kPatchLoads]) {
+        const uint32_t pk = __builtin_amdgcn_readfirstlane(s_pk[kp]);
+        const uint8_t* cb = blur + (uint64_t)(pt_y(pk) + kBorder) * bp + (pt_x(pk) + kBorder);
+#pragma unroll
+        for (int t = 0; t < kPatchLoads; ++t) reg[t] = *reinterpret_cast<const desc_u32_unaligned*>(cb + pr_off[t]);
+    };
+    const int cnt_c = max(0, min(cnt, kp_cap - (base_out + kp0)));
+    uint32_t nreg[kPatchLoads];
+    if (cnt_c > 0) fetch(kp0, nreg);
+    for (int q = 0; q < cnt_c; ++q) {
+        const int kp = kp0 + q;
+        __builtin_amdgcn_wave_barrier();  // the previous keypoint's LDS reads are done (same wave, in order)
+#pragma unroll
+        for (int t = 0; t < kPatchLoads; ++t) *reinterpret_cast<uint32_t*>(my_patch + pr_lds[t]) = nreg[t];
+        if (q + 1 < cnt_c) fetch(kp + 1, nreg);
+        __builtin_amdgcn_wave_barrier();
+        const float a = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_a[kp])));
+        const float b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_b[kp])));
+        const uint8_t* pc = my_patch + 18 * kPatchPitch + 18;
+        int val[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            // the reference's -march=native build contracts x*b + y*a and x*a - y*b into one fma
+            const int row = (int)rintf(__fmaf_rn(pat_x[e], b, __fmul_rn(pat_y[e], a)));
+            const int col = (int)rintf(__fmaf_rn(pat_x[e], a, -__fmul_rn(pat_y[e], b)));
+            val[e] = pc[row * kPatchPitch + col];
+        }
+        uint32_t bits = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bits |= (val[2 * t] < val[2 * t + 1] ? 1u : 0u) << t;
+        const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0xB1, 0xF, 0xF, true);  // lane ^ 1
+        uint8_t* dsc = out_desc + ((uint64_t)frame * kp_cap + base_out + kp) * 32;
+        if ((lane & 1) == 0) dsc[lane >> 1] = (uint8_t)(bits | (other << 4));
     }
 }
 

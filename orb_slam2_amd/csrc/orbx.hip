@@ -53,7 +53,7 @@ struct orbx_ctx {
     size_t oct_lds = 0;
 
     // device tables
-    DevBuf d_cells, d_tiles, d_ic, d_pat;
+    DevBuf d_cells, d_tiles, d_pat;
     DevBuf d_xt[ORBX_MAX_LEVELS], d_yt[ORBX_MAX_LEVELS];
     // device arenas (grown on demand)
     DevBuf d_pyr, d_blur, d_cand, d_ccount, d_dense_pts, d_dense_node, d_lvl_kps, d_lvl_count;
@@ -302,11 +302,11 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     if (prof) HIP_TRY(c, hipEventRecord(c->ev[4], st));
     // stage 4: orientation + descriptors + output assembly
     {
-        const int kp_blocks = (c->max_kp_level + 3) / 4;
+        const int kp_blocks = (c->max_kp_level + kDescKp - 1) / kDescKp;
         const unsigned grid = 8u * (unsigned)((n + 7) / 8) * (unsigned)L * (unsigned)kp_blocks;
         hipLaunchKernelGGL(k_orient_describe, dim3(grid), dim3(256), 0, st, B, (const uint32_t*)c->d_lvl_kps.p,
-                           (const int32_t*)c->d_lvl_count.p, (const int8_t*)c->d_ic.p, (const int8_t*)c->d_pat.p,
-                           d_kps, d_desc, d_n_out, kp_cap, kp_blocks);
+                           (const int32_t*)c->d_lvl_count.p, (const int8_t*)c->d_pat.p, d_kps, d_desc, d_n_out, kp_cap,
+                           kp_blocks);
     }
     if (prof) {
         HIP_TRY(c, hipEventRecord(c->ev[5], st));
@@ -358,17 +358,7 @@ extern "C" int orbx_create(const orbx_params* params, orbx_ctx** out) {
     for (int i = 0; i <= ORBX_NUM_STAGES; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(ORBX_E_HIP);
     c->ev_made = true;
-    // orientation disc: (u, v) for every pixel with |u| <= umax[|v|]
-    std::vector<int8_t> ic;
-    for (int v = -kHalfPatch; v <= kHalfPatch; ++v)
-        for (int u = -tab.umax[std::abs(v)]; u <= tab.umax[std::abs(v)]; ++u) {
-            ic.push_back((int8_t)u);
-            ic.push_back((int8_t)v);
-        }
-    if ((int)ic.size() != 2 * kIcCount) return fail(ORBX_E_INVALID);
-    if ((rc = ensure(c, &c->d_ic, ic.size()))) return fail(rc);
     if ((rc = ensure(c, &c->d_pat, sizeof(kPattern)))) return fail(rc);
-    if (hipMemcpy(c->d_ic.p, ic.data(), ic.size(), hipMemcpyHostToDevice) != hipSuccess) return fail(ORBX_E_HIP);
     if (hipMemcpy(c->d_pat.p, kPattern, sizeof(kPattern), hipMemcpyHostToDevice) != hipSuccess) return fail(ORBX_E_HIP);
     // size everything for the largest image and batch now, so steady-state calls do not allocate
     if ((rc = set_geometry(c, params->max_width, params->max_height))) return fail(rc);
@@ -385,7 +375,7 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->prm.device_id);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->d_cells, &c->d_tiles, &c->d_ic, &c->d_pat, &c->d_pyr, &c->d_blur, &c->d_cand, &c->d_ccount,
+    DevBuf* bufs[] = {&c->d_cells, &c->d_tiles, &c->d_pat, &c->d_pyr, &c->d_blur, &c->d_cand, &c->d_ccount,
                       &c->d_dense_pts, &c->d_dense_node, &c->d_lvl_kps, &c->d_lvl_count, &c->d_out_kps,
                       &c->d_out_desc, &c->d_out_n};
     for (DevBuf* b : bufs) release(b);
