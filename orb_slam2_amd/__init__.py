@@ -57,9 +57,10 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("ORBX_LIB", LIB_PATH)  # ORBX_LIB: a diagnostic build of the same library
+    if not os.path.exists(path):
         raise OrbxError("liborbx.so not built: run `make -C orb_slam2_amd/csrc` (or __graft_entry__.build())")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
     L.orbx_host_tables.argtypes = [i32, f32, i32, vp, vp, vp, vp, vp, vp]
     L.orbx_host_level_geometry.argtypes = [i32, f32, i32, i32, i32, i32, C.POINTER(LevelGeom)]

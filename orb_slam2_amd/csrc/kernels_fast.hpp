@@ -66,31 +66,106 @@ constexpr int kFastMaxCell = 66;  // largest sub-image side: wCell <= 59, + 6, +
 
 // LDS carve-up of k_fast_tiles for one tile geometry (bytes).
 struct FastLds {
-    int tile, plane, queue;
+    int tile, plane, queue, kept;
 };
 // Tile layout: LDS column of detection column u is u + 4, so u = 0 sits on a dword boundary and
 // the 3-pixel halo on its left occupies columns 1..3.  Four spare columns on the right keep the
 // reads of the (discarded) pixels between wd and the next multiple of 4 inside the row.
-__host__ __device__ inline int fast_tile_pitch(int wd) { return (wd + 14 + 3) & ~3; }
+__host__ __device__ inline int fast_tile_pitch(int wd) { return (wd + 14 + 15) & ~15; }
 __host__ __device__ inline int fast_plane_pitch(int wd, int nc) { return (wd + nc + 1 + 3) & ~3; }
+// Queue entries for both ends together.  Half a tile's pixels is far above what textured images
+// produce (about 15 %); a tile that overflows falls back to scoring every pixel.
+__host__ __device__ inline int fast_queue_cap(int wd, int hd) { return (((wd + 3) & ~3) * hd) / 2; }
+__host__ __device__ inline int fast_kept_cap(int wd, int hd) { return (((wd + 3) & ~3) * hd) / 8 + 64; }
 __host__ __device__ inline FastLds fast_lds_need(int wd, int hd, int nc) {
     FastLds n;
     n.tile = fast_tile_pitch(wd) * (hd + 6) + 16;
     n.plane = fast_plane_pitch(wd, nc) * (hd + 2);
-    n.queue = (((wd + 3) & ~3) * hd) * 2;
+    n.queue = fast_queue_cap(wd, hd) * 2;
+    n.kept = fast_kept_cap(wd, hd) * 2;
     return n;
 }
 
 typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+struct __attribute__((packed, aligned(1))) uint4_unaligned {
+    uint32_t x, y, z, w;
+    __device__ operator uint4() const { return make_uint4(x, y, z, w); }
+};
+constexpr int kFastStageDepth = 3;  // 16-byte loads in flight per thread while staging a tile
+
+// Diagnostic build only (-DORBX_STAMPS): wave 0 adds the cycles between phase boundaries into
+// B.stamps[phase]; the product build compiles these calls away.
+#ifdef ORBX_STAMPS
+#define ORBX_STAMP(B, slot, t0)                                                                   \
+    do {                                                                                          \
+        const unsigned long long t1_ = __builtin_amdgcn_s_memtime();                               \
+        if (threadIdx.x == 0 && (B).stamps) atomicAdd(&(B).stamps[slot], t1_ - (t0));              \
+        (t0) = __builtin_amdgcn_s_memtime();                                                       \
+    } while (0)
+#else
+#define ORBX_STAMP(B, slot, t0) do { (void)(t0); } while (0)
+#endif
+
+struct FastShared {  // small per-workgroup state in static LDS
+    int q_front, q_back, n_kept, retry;
+    int kept[kFastTileCells];
+    int th[kFastTileCells];
+};
+
+// Full segment-test half score of the queued pixels in [q_lo, q_hi): ring darker than the centre
+// (DARK_RING = true, a "bright" corner) or ring brighter (evaluated as ring - centre).
+template <bool BRIGHT, bool RETRY>
+__device__ __forceinline__ void fast_score_range(const uint8_t* s_tile, uint8_t* s_score, const uint16_t* s_queue,
+                                                 const FastShared* sh, int q_lo, int q_hi, int TP, int SP, int wd, int nc,
+                                                 float inv_wcell, int thr) {
+    for (int q = q_lo + (int)threadIdx.x; q < q_hi; q += 256) {
+        const int e = s_queue[q], u = e & 0xFF, vq = e >> 8;
+        if (u >= wd) continue;  // padding pixels of the last dword of a row
+        const uint8_t* p = s_tile + (vq + 3) * TP + 4 + u;
+        const int cv = p[0];
+        int r[16];
+        r[0] = p[3 * TP];
+        r[1] = p[3 * TP + 1];
+        r[2] = p[2 * TP + 2];
+        r[3] = p[1 * TP + 3];
+        r[4] = p[3];
+        r[5] = p[-1 * TP + 3];
+        r[6] = p[-2 * TP + 2];
+        r[7] = p[-3 * TP + 1];
+        r[8] = p[-3 * TP];
+        r[9] = p[-3 * TP - 1];
+        r[10] = p[-2 * TP - 2];
+        r[11] = p[-1 * TP - 3];
+        r[12] = p[-3];
+        r[13] = p[1 * TP - 3];
+        r[14] = p[2 * TP - 2];
+        r[15] = p[3 * TP - 1];
+        int d[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d[k] = BRIGHT ? cv - r[k] : r[k] - cv;
+        const int S = arc_max(d);
+        if (S > thr) {
+            const int c = min((int)(((float)u + 0.5f) * inv_wcell), nc - 1);
+            if (!RETRY || sh->th[c] >= 0) s_score[(vq + 1) * SP + 1 + u + c] = (uint8_t)(S - 1);
+        }
+    }
+}
 
 // Steps 1-3 of one pass over a tile (see k_fast_tiles).  RETRY = false: threshold iniTh, every
-// cell; RETRY = true: threshold minTh, only the cells whose s_th entry is >= 0.
+// cell; RETRY = true: threshold minTh, only the cells whose th entry is >= 0.
 template <bool RETRY>
-__device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_score, uint8_t* s_keep, uint16_t* s_queue,
-                                          int* s_qn, int* s_kept, const int* s_th, int TP, int SP, int wd, int hd,
-                                          int nc, int w_cell, float inv_wcell, int thr) {
+__device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_score, uint16_t* s_queue, uint16_t* s_keptl,
+                                          FastShared* sh, int TP, int SP, int wd, int hd, int nc, float inv_wcell,
+                                          int thr, int q_cap, int k_cap, const BatchDev& B, int stamp_base) {
     const int tid = threadIdx.x, lane = tid & 63;
-    if (tid == 0) *s_qn = 0;
+    unsigned long long t0 = 0;
+#ifdef ORBX_STAMPS
+    t0 = __builtin_amdgcn_s_memtime();
+#endif
+    if (tid == 0) {
+        sh->q_front = 0;
+        sh->q_back = 0;
+    }
     __syncthreads();
     // ---- 1. rejection test, four pixels per work item, two pixels per instruction ----
     // Any arc of 9 holds one pixel of each opposite pair, so a corner needs the two compass pairs
@@ -98,6 +173,8 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
     // dword's bytes are split into even and odd pixels as two 16-bit lanes; with the centre biased
     // by 256 a plain 32-bit subtract yields both lanes' differences, packed u16 min/max combine
     // the pairs, and adding a constant moves "beyond the threshold" into bit 15 of each lane.
+    // Pixels whose ring is darker go to the front of the queue, brighter ones to its back, so that
+    // step 2 runs each half of the score on a dense range.
     const int ndwd = (wd + 3) >> 2, n_items = hd * ndwd;
     const uint32_t kM = 0x00FF00FFu, kBias = 0x01000100u;
     const uint32_t add_bright = (uint32_t)(0x8000 - 257 - thr) * 0x00010001u;
@@ -107,7 +184,7 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
     int j = tid - v * ndwd;
     const int dv = 256 / ndwd, dj = 256 - dv * ndwd;
     for (int i0 = 0; i0 < n_items; i0 += 256) {
-        uint32_t pe = 0, po = 0;  // bit 15 / 31 of pe: pixels 0 / 2 pass; of po: pixels 1 / 3
+        uint32_t pb[2] = {0, 0}, pd[2] = {0, 0};  // [0]: bits 15/31 = pixels 0/2, [1]: pixels 1/3
         if (v < hd) {
             const uint8_t* pc = s_tile + (v + 3) * TP + 4 * j + 4;
             const uint32_t Cd = *reinterpret_cast<const uint32_t*>(pc);
@@ -115,46 +192,49 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
             const uint32_t Dd = *reinterpret_cast<const uint32_t*>(pc - 3 * TP);
             const uint32_t Rd = *reinterpret_cast<const u32_unaligned*>(pc + 3);
             const uint32_t Ld = *reinterpret_cast<const u32_unaligned*>(pc - 3);
-            uint32_t ps[2];
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {  // 0: pixels 0,2   1: pixels 1,3
-                const int sh = 8 * h2;
-                const uint32_t c = ((Cd >> sh) & kM) | kBias;
-                const uint32_t d0 = c - ((Ud >> sh) & kM), d8 = c - ((Dd >> sh) & kM);
-                const uint32_t d4 = c - ((Rd >> sh) & kM), d12 = c - ((Ld >> sh) & kM);
-                const uint32_t br = pk_min_u16(pk_max_u16(d0, d8), pk_max_u16(d4, d12));
-                const uint32_t dk = pk_max_u16(pk_min_u16(d0, d8), pk_min_u16(d4, d12));
-                ps[h2] = ((br + add_bright) | (sub_dark - dk)) & 0x80008000u;
-            }
-            pe = ps[0];
-            po = ps[1];
+            uint32_t on[2] = {0x80008000u, 0x80008000u};
             if (RETRY) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int u = min(4 * j + b, wd - 1);
-                    const bool on = s_th[min((int)(((float)u + 0.5f) * inv_wcell), nc - 1)] >= 0;
-                    if (!on) {
-                        if (b & 1) po &= ~(0x8000u << (8 * (b & 2)));
-                        else pe &= ~(0x8000u << (8 * (b & 2)));
-                    }
+                    if (sh->th[min((int)(((float)u + 0.5f) * inv_wcell), nc - 1)] < 0) on[b & 1] &= ~(0x8000u << (8 * (b & 2)));
                 }
             }
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {  // 0: pixels 0,2   1: pixels 1,3
+                const int sft = 8 * h2;
+                const uint32_t c = ((Cd >> sft) & kM) | kBias;
+                const uint32_t d0 = c - ((Ud >> sft) & kM), d8 = c - ((Dd >> sft) & kM);
+                const uint32_t d4 = c - ((Rd >> sft) & kM), d12 = c - ((Ld >> sft) & kM);
+                const uint32_t br = pk_min_u16(pk_max_u16(d0, d8), pk_max_u16(d4, d12));
+                const uint32_t dk = pk_max_u16(pk_min_u16(d0, d8), pk_min_u16(d4, d12));
+                pb[h2] = (br + add_bright) & on[h2];
+                pd[h2] = (sub_dark - dk) & on[h2];
+            }
         }
-        // wave-level append; entry = v << 8 | u
-        const uint64_t m0 = __ballot((pe & 0x8000u) != 0), m1 = __ballot((po & 0x8000u) != 0),
-                       m2 = __ballot((int)pe < 0), m3 = __ballot((int)po < 0);
-        const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
-        const int tot = n0 + n1 + n2 + n3;
-        if (tot) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(s_qn, tot);
-            base = __builtin_amdgcn_readfirstlane(base);
-            const uint64_t below = (1ull << lane) - 1ull;
-            const int e0 = (v << 8) + 4 * j;
-            if (pe & 0x8000u) s_queue[base + __popcll(m0 & below)] = (uint16_t)(e0 + 0);
-            if (po & 0x8000u) s_queue[base + n0 + __popcll(m1 & below)] = (uint16_t)(e0 + 1);
-            if ((int)pe < 0) s_queue[base + n0 + n1 + __popcll(m2 & below)] = (uint16_t)(e0 + 2);
-            if ((int)po < 0) s_queue[base + n0 + n1 + n2 + __popcll(m3 & below)] = (uint16_t)(e0 + 3);
+        const int e0 = (v << 8) + 4 * j;
+        const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const uint32_t pe = side ? pd[0] : pb[0], po = side ? pd[1] : pb[1];
+            const uint64_t m0 = __ballot((pe & 0x8000u) != 0), m1 = __ballot((po & 0x8000u) != 0),
+                           m2 = __ballot((int)pe < 0), m3 = __ballot((int)po < 0);
+            const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+            const int tot = n0 + n1 + n2 + n3;
+            if (tot) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(side ? &sh->q_back : &sh->q_front, tot);
+                base = __builtin_amdgcn_readfirstlane(base);
+                // front grows upwards from 0, back grows downwards from q_cap - 1
+                const int sg = side ? -1 : 1, org = side ? q_cap - 1 - base : base;
+                // positions beyond the buffer are dropped; the overflow is detected after the loop
+                const int r0 = __popcll(m0 & below), r1 = n0 + __popcll(m1 & below), r2 = n0 + n1 + __popcll(m2 & below),
+                          r3 = n0 + n1 + n2 + __popcll(m3 & below);
+                if ((pe & 0x8000u) && base + r0 < q_cap) s_queue[org + sg * r0] = (uint16_t)(e0 + 0);
+                if ((po & 0x8000u) && base + r1 < q_cap) s_queue[org + sg * r1] = (uint16_t)(e0 + 1);
+                if ((int)pe < 0 && base + r2 < q_cap) s_queue[org + sg * r2] = (uint16_t)(e0 + 2);
+                if ((int)po < 0 && base + r3 < q_cap) s_queue[org + sg * r3] = (uint16_t)(e0 + 3);
+            }
         }
         v += dv;
         j += dj;
@@ -164,158 +244,234 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
         }
     }
     __syncthreads();
-    const int qn = *s_qn;
-    // ---- 2. full score for the queued pixels ----
-    for (int q = tid; q < qn; q += 256) {
-        const int e = s_queue[q], u = e & 0xFF, vq = e >> 8;
-        if (u >= wd) continue;  // padding pixels of the last dword of a row
-        const uint8_t* p = s_tile + (vq + 3) * TP + 4 + u;
-        const int c0 = p[0];
-        const int r0 = p[3 * TP], r8 = p[-3 * TP], r4 = p[3], r12 = p[-3];
-        // side of the test this pixel passed: ring darker than the centre (bright corner) or
-        // brighter (dark corner, evaluated on inverted pixels); both is possible but rare
-        const bool bright = min(max(c0 - r0, c0 - r8), max(c0 - r4, c0 - r12)) > thr;
-        const bool dark = max(min(c0 - r0, c0 - r8), min(c0 - r4, c0 - r12)) < -thr;
-        int S = -256;
-        for (int side = 0; side < 2; ++side) {
-            if (side == 0 ? !bright : !dark) continue;
-            const int flip = side ? 0xFF : 0;
-            const int cv = c0 ^ flip;
-            int d[16];
-            d[0] = cv - (r0 ^ flip);
-            d[1] = cv - (p[3 * TP + 1] ^ flip);
-            d[2] = cv - (p[2 * TP + 2] ^ flip);
-            d[3] = cv - (p[1 * TP + 3] ^ flip);
-            d[4] = cv - (r4 ^ flip);
-            d[5] = cv - (p[-1 * TP + 3] ^ flip);
-            d[6] = cv - (p[-2 * TP + 2] ^ flip);
-            d[7] = cv - (p[-3 * TP + 1] ^ flip);
-            d[8] = cv - (r8 ^ flip);
-            d[9] = cv - (p[-3 * TP - 1] ^ flip);
-            d[10] = cv - (p[-2 * TP - 2] ^ flip);
-            d[11] = cv - (p[-1 * TP - 3] ^ flip);
-            d[12] = cv - (r12 ^ flip);
-            d[13] = cv - (p[1 * TP - 3] ^ flip);
-            d[14] = cv - (p[2 * TP - 2] ^ flip);
-            d[15] = cv - (p[3 * TP - 1] ^ flip);
-            S = max(S, arc_max(d));
-        }
-        if (S > thr) {
+    ORBX_STAMP(B, stamp_base + 0, t0);
+    const int qf = sh->q_front, qb = sh->q_back;
+    if (qf + qb > q_cap) {
+        // queue overflow (a tile of dense noise): score every pixel on both sides, no survivors list;
+        // the output stage then finds the maxima by scanning the score plane
+        for (int i = tid; i < wd * hd; i += 256) {
+            const int vq = (int)(((float)i + 0.5f) * (1.0f / (float)wd)), u = i - vq * wd;
             const int c = min((int)(((float)u + 0.5f) * inv_wcell), nc - 1);
-            if (!RETRY || s_th[c] >= 0) s_score[(vq + 1) * SP + 1 + u + c] = (uint8_t)(S - 1);
+            if (RETRY && sh->th[c] < 0) continue;
+            const uint8_t* p = s_tile + (vq + 3) * TP + 4 + u;
+            const int cv = p[0];
+            const int r[16] = {p[3 * TP], p[3 * TP + 1], p[2 * TP + 2], p[TP + 3], p[3], p[-TP + 3], p[-2 * TP + 2], p[-3 * TP + 1],
+                               p[-3 * TP], p[-3 * TP - 1], p[-2 * TP - 2], p[-TP - 3], p[-3], p[TP - 3], p[2 * TP - 2], p[3 * TP - 1]};
+            int d[16], g[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                d[k] = cv - r[k];
+                g[k] = r[k] - cv;
+            }
+            const int S = max(arc_max(d), arc_max(g));
+            if (S > thr) s_score[(vq + 1) * SP + 1 + u + c] = (uint8_t)(S - 1);
         }
+        __syncthreads();
+        // count the maxima per cell (the retry decision needs the counts)
+        for (int i = tid; i < wd * hd; i += 256) {
+            const int vq = (int)(((float)i + 0.5f) * (1.0f / (float)wd)), u = i - vq * wd;
+            const int c = min((int)(((float)u + 0.5f) * inv_wcell), nc - 1);
+            if (RETRY && sh->th[c] < 0) continue;
+            const uint8_t* sp = s_score + (vq + 1) * SP + 1 + u + c;
+            const int sc = sp[0];
+            if (sc > 0) {
+                const int m = max(max(max((int)sp[-1], (int)sp[1]), max((int)sp[-SP - 1], (int)sp[-SP])),
+                                  max(max((int)sp[-SP + 1], (int)sp[SP - 1]), max((int)sp[SP], (int)sp[SP + 1])));
+                if (sc > m) atomicAdd(&sh->kept[c], 1);
+            }
+        }
+        if (tid == 0) sh->n_kept = 1 << 24;  // forces the scanning output path
+        __syncthreads();
+        return;
     }
+    // ---- 2. full score of the queued pixels ----
+    fast_score_range<true, RETRY>(s_tile, s_score, s_queue, sh, 0, qf, TP, SP, wd, nc, inv_wcell, thr);
+    fast_score_range<false, RETRY>(s_tile, s_score, s_queue, sh, q_cap - qb, q_cap, TP, SP, wd, nc, inv_wcell, thr);
     __syncthreads();
-    // ---- 3. non-max suppression of the queued pixels ----
-    for (int q = tid; q < qn; q += 256) {
-        const int e = s_queue[q], u = e & 0xFF, vq = e >> 8;
-        if (u >= wd) continue;
-        const int c = min((int)(((float)u + 0.5f) * inv_wcell), nc - 1);
-        const uint8_t* sp = s_score + (vq + 1) * SP + 1 + u + c;
-        const int sc = sp[0];
-        if (sc > 0) {
-            const int m = max(max(max((int)sp[-1], (int)sp[1]), max((int)sp[-SP - 1], (int)sp[-SP])),
-                              max(max((int)sp[-SP + 1], (int)sp[SP - 1]), max((int)sp[SP], (int)sp[SP + 1])));
-            if (sc > m) {
-                s_keep[(vq + 1) * SP + 1 + u + c] = 1;
-                atomicAdd(&s_kept[c], 1);
+    ORBX_STAMP(B, stamp_base + 1, t0);
+    // ---- 3. non-max suppression of the queued pixels; survivors are listed and counted per cell ----
+    const int n_all = qf + qb;
+    for (int q0 = 0; q0 < n_all; q0 += 256) {
+        const int q = q0 + tid;
+        bool keep = false;
+        int ke = 0, c = 0;
+        if (q < n_all) {
+            const int e = s_queue[q < qf ? q : q_cap - qb + (q - qf)], u = e & 0xFF, vq = e >> 8;
+            if (u < wd) {
+                c = min((int)(((float)u + 0.5f) * inv_wcell), nc - 1);
+                const uint8_t* sp = s_score + (vq + 1) * SP + 1 + u + c;
+                const int sc = sp[0];
+                if (sc > 0) {
+                    const int m = max(max(max((int)sp[-1], (int)sp[1]), max((int)sp[-SP - 1], (int)sp[-SP])),
+                                      max(max((int)sp[-SP + 1], (int)sp[SP - 1]), max((int)sp[SP], (int)sp[SP + 1])));
+                    keep = sc > m;
+                    ke = (c << 14) | e;
+                }
+            }
+        }
+        // a pixel queued on both sides is listed once: the back copy is dropped when the front one exists
+        if (keep && q >= qf) {
+            const uint8_t* p = s_tile + ((ke >> 8 & 0x3F) + 3) * TP + 4 + (ke & 0xFF);
+            const int cv = p[0];
+            const bool also_front = min(max(cv - (int)p[3 * TP], cv - (int)p[-3 * TP]), max(cv - (int)p[3], cv - (int)p[-3])) > thr;
+            keep = !also_front;
+        }
+        const uint64_t m = __ballot(keep);
+        if (m) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&sh->n_kept, __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (keep) {
+                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (pos < k_cap) s_keptl[pos] = (uint16_t)ke;
+                atomicAdd(&sh->kept[c], 1);
             }
         }
     }
     __syncthreads();
+    ORBX_STAMP(B, stamp_base + 2, t0);
 }
 
 // One workgroup per tile (a run of up to kFastTileCells cells of one cell row).
-// grid = (tiles, frames), block = 256, dynamic LDS = tile + 2 planes + queue.
+// grid = (tiles, frames), block = 256, dynamic LDS = tile + score plane + queue + kept list.
 //  pass 0, threshold iniTh, all cells of the tile:
 //   1. every detection pixel takes the compass-pair rejection test; survivors go to an LDS queue;
 //   2. queued pixels get the full segment-test score S; S > t stores score S-1 in a score plane
 //      in which the cells are separated by a zero column, so that
 //   3. strict 3x3 non-max suppression over the plane is cell-local exactly as when cv::FAST runs
-//      on the cell's sub-image; survivors are flagged and counted per cell;
+//      on the cell's sub-image; survivors are listed and counted per cell;
 //  pass 1, threshold minTh, only the cells whose pass-0 count is zero (the retry of
 //      reference :903-907), same three steps;
-//  then each wave compacts the flags of its cells in row-major order into the cell's slot.
+//  then the survivors are written to their cell's slot in row-major order: each one's position
+//  is its rank among the listed survivors (the list key is cell | row | column).
 __global__ __launch_bounds__(256) void k_fast_tiles(BatchDev B, const TileDesc* __restrict__ tiles,
                                                     uint32_t* __restrict__ cand, uint32_t* __restrict__ ccount,
-                                                    int tile_bytes, int plane_bytes) {
+                                                    int tile_bytes, int plane_bytes, int queue_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
-    __shared__ int s_qn;
-    __shared__ int s_kept[kFastTileCells];
-    __shared__ int s_th[kFastTileCells];
-    __shared__ int s_retry;
+    __shared__ FastShared sh;
 
     uint8_t* s_tile = s_mem;
     uint8_t* s_score = s_mem + tile_bytes;
-    uint8_t* s_keep = s_score + plane_bytes;
-    uint16_t* s_queue = reinterpret_cast<uint16_t*>(s_keep + plane_bytes);
+    uint16_t* s_queue = reinterpret_cast<uint16_t*>(s_score + plane_bytes);
+    uint16_t* s_keptl = reinterpret_cast<uint16_t*>(s_score + plane_bytes + queue_bytes);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const TileDesc td = tiles[blockIdx.x];
     const LevelDev& L = B.lv[td.level];
     const uint8_t* img = L.img + (uint64_t)blockIdx.y * L.plane;
     const int wd = td.wd, hd = td.hd, nc = td.nc, w_cell = td.w_cell;
-    const int TP = fast_tile_pitch(wd), ndw = TP >> 2;
+    const int TP = fast_tile_pitch(wd);
     const int SP = fast_plane_pitch(wd, nc);
     const int rows = hd + 6, y_top = td.y_first - 3, x_left = td.x_first - 4;
-    const float inv_ndw = 1.0f / (float)ndw;
     const float inv_wcell = 1.0f / (float)w_cell;
+    const int q_cap = fast_queue_cap(wd, hd), k_cap = fast_kept_cap(wd, hd);
+    unsigned long long t0 = 0;
+#ifdef ORBX_STAMPS
+    t0 = __builtin_amdgcn_s_memtime();
+#endif
 
-    // stage the tile: LDS dword c of a row <- the (unaligned) global dword at x_left + 4c
-    const int row_end = L.pitch - 4;  // last dword that still starts inside the row
-    for (int i = tid; i < rows * ndw; i += 256) {
-        const int r = (int)(((float)i + 0.5f) * inv_ndw), c = i - r * ndw;
-        const int col = min(x_left + 4 * c, row_end);
-        const uint32_t v = *reinterpret_cast<const u32_unaligned*>(img + (uint64_t)(y_top + r) * L.pitch + col);
-        *reinterpret_cast<uint32_t*>(&s_tile[r * TP + 4 * c]) = v;
-    }
-    for (int i = tid; i < (2 * plane_bytes) >> 2; i += 256) reinterpret_cast<uint32_t*>(s_score)[i] = 0;  // score + keep
-    if (tid < kFastTileCells) {
-        s_kept[tid] = 0;
-        s_th[tid] = 0;
-    }
-    if (tid == 0) s_retry = 0;
-    __syncthreads();
-
-    fast_pass<false>(s_tile, s_score, s_keep, s_queue, &s_qn, s_kept, s_th, TP, SP, wd, hd, nc, w_cell, inv_wcell,
-                     B.ini_th);
-    if (tid < nc) {
-        const bool retry = s_kept[tid] == 0;
-        s_th[tid] = retry ? 0 : -1;
-        if (retry) s_retry = 1;
-    }
-    __syncthreads();
-    if (s_retry)
-        fast_pass<true>(s_tile, s_score, s_keep, s_queue, &s_qn, s_kept, s_th, TP, SP, wd, hd, nc, w_cell, inv_wcell,
-                        B.min_th);
-
-    // ---- ordered compaction: wave w takes cells w, w+4, ... ----
-    for (int c = wave; c < nc; c += 4) {
-        const int cwd = c < nc - 1 ? w_cell : wd - (nc - 1) * w_cell;
-        const int npx = cwd * hd;
-        const float inv_cwd = 1.0f / (float)cwd;
-        const uint64_t slot = (uint64_t)blockIdx.y * B.total_cells + td.slot0 + c;
-        uint32_t* out = cand + slot * B.cell_cap;
-        int base = 0;
-        for (int i0 = 0; i0 < npx; i0 += 64) {
-            const int i = i0 + lane;
-            int keep = 0, px = 0, py = 0, pidx = 0;
-            if (i < npx) {
-                py = (int)(((float)i + 0.5f) * inv_cwd);
-                px = i - py * cwd;
-                pidx = (py + 1) * SP + 1 + c * (w_cell + 1) + px;
-                keep = s_keep[pidx];
+    // stage the tile: 16-byte chunk c of an LDS row <- the 16 (unaligned) global bytes at
+    // x_left + 16c.  All of a thread's loads are issued before the first LDS write, so a tile
+    // costs one memory round trip, not one per chunk.
+    {
+        const int nch = TP >> 4, total = rows * nch;
+        const int row_end = L.pitch - 16;  // last chunk start that keeps the load inside the row
+        const float inv_nch = 1.0f / (float)nch;
+        for (int i0 = 0; i0 < total; i0 += 256 * kFastStageDepth) {
+            uint4 reg[kFastStageDepth];
+            int dst[kFastStageDepth];
+#pragma unroll
+            for (int k = 0; k < kFastStageDepth; ++k) {
+                const int i = i0 + 256 * k + tid;
+                dst[k] = -1;
+                if (i < total) {
+                    const int r = (int)(((float)i + 0.5f) * inv_nch), c = i - r * nch;
+                    const int col = min(x_left + 16 * c, row_end);
+                    reg[k] = *reinterpret_cast<const uint4_unaligned*>(img + (uint64_t)(y_top + r) * L.pitch + col);
+                    dst[k] = r * TP + 16 * c;
+                }
             }
-            const uint64_t m = __ballot(keep);
-            if (keep) {
-                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-                if (pos < B.cell_cap)
-                    out[pos] = pack_pt(td.off_x + c * w_cell + px, td.off_y + py, s_score[pidx]);
-            }
-            base += __popcll(m);
+#pragma unroll
+            for (int k = 0; k < kFastStageDepth; ++k)
+                if (dst[k] >= 0) *reinterpret_cast<uint4*>(&s_tile[dst[k]]) = reg[k];
         }
-        if (lane == 0) ccount[slot] = (uint32_t)min(base, B.cell_cap);
     }
+    for (int i = tid; i < plane_bytes >> 2; i += 256) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
+    if (tid < kFastTileCells) {
+        sh.kept[tid] = 0;
+        sh.th[tid] = 0;
+    }
+    if (tid == 0) {
+        sh.retry = 0;
+        sh.n_kept = 0;
+    }
+    __syncthreads();
+    ORBX_STAMP(B, 0, t0);
+
+    fast_pass<false>(s_tile, s_score, s_queue, s_keptl, &sh, TP, SP, wd, hd, nc, inv_wcell, B.ini_th, q_cap, k_cap, B, 1);
+    if (tid < nc) {
+        const bool retry = sh.kept[tid] == 0;
+        sh.th[tid] = retry ? 0 : -1;
+        if (retry) sh.retry = 1;
+    }
+    __syncthreads();
+    if (sh.retry)
+        fast_pass<true>(s_tile, s_score, s_queue, s_keptl, &sh, TP, SP, wd, hd, nc, inv_wcell, B.min_th, q_cap, k_cap, B, 4);
+
+    // ---- ordered output ----
+#ifdef ORBX_STAMPS
+    t0 = __builtin_amdgcn_s_memtime();
+#endif
+    const uint64_t slot0 = (uint64_t)blockIdx.y * B.total_cells + td.slot0;
+    const int nk = sh.n_kept;
+    if (nk <= 256 && nk <= k_cap) {
+        // rank among the listed survivors = position in (cell, row, column) order
+        if (tid < nk) {
+            const int e = s_keptl[tid];
+            int rank = 0;
+            for (int jx = 0; jx < nk; ++jx) rank += (int)s_keptl[jx] < e ? 1 : 0;
+            const int c = e >> 14, vq = (e >> 8) & 0x3F, u = e & 0xFF;
+            int start = 0;
+            for (int cc = 0; cc < c; ++cc) start += sh.kept[cc];
+            const int pos = rank - start;
+            if (pos < B.cell_cap)
+                cand[(slot0 + c) * B.cell_cap + pos] = pack_pt(td.off_x + u, td.off_y + vq, s_score[(vq + 1) * SP + 1 + u + c]);
+        }
+        if (tid < nc) ccount[slot0 + tid] = (uint32_t)min(sh.kept[tid], B.cell_cap);
+    } else {
+        // dense tiles: wave w scans cells w, w+4, ... in row-major order and repeats the suppression test
+        for (int c = wave; c < nc; c += 4) {
+            const int cwd = c < nc - 1 ? w_cell : wd - (nc - 1) * w_cell;
+            const int npx = cwd * hd;
+            const float inv_cwd = 1.0f / (float)cwd;
+            uint32_t* out = cand + (slot0 + c) * B.cell_cap;
+            int base = 0;
+            for (int i0 = 0; i0 < npx; i0 += 64) {
+                const int i = i0 + lane;
+                bool keep = false;
+                int px = 0, py = 0, sc = 0;
+                if (i < npx) {
+                    py = (int)(((float)i + 0.5f) * inv_cwd);
+                    px = i - py * cwd;
+                    const uint8_t* sp = s_score + (py + 1) * SP + 1 + c * (w_cell + 1) + px;
+                    sc = sp[0];
+                    if (sc > 0) {
+                        const int m = max(max(max((int)sp[-1], (int)sp[1]), max((int)sp[-SP - 1], (int)sp[-SP])),
+                                          max(max((int)sp[-SP + 1], (int)sp[SP - 1]), max((int)sp[SP], (int)sp[SP + 1])));
+                        keep = sc > m;
+                    }
+                }
+                const uint64_t m = __ballot(keep);
+                if (keep) {
+                    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < B.cell_cap) out[pos] = pack_pt(td.off_x + c * w_cell + px, td.off_y + py, sc);
+                }
+                base += __popcll(m);
+            }
+            if (lane == 0) ccount[slot0 + c] = (uint32_t)min(base, B.cell_cap);
+        }
+    }
+    ORBX_STAMP(B, 7, t0);
 }
 
 }  // namespace orbx

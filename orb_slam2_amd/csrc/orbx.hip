@@ -45,7 +45,7 @@ struct orbx_ctx {
     std::vector<CellDesc> cells;
     std::vector<TileDesc> tiles;
     int rs_pitch[ORBX_MAX_LEVELS], rs_rows[ORBX_MAX_LEVELS];  // resize source tile in LDS
-    int fast_tile_bytes = 0, fast_plane_bytes = 0;
+    int fast_tile_bytes = 0, fast_plane_bytes = 0, fast_queue_bytes = 0;
     size_t fast_lds = 0;
     int pitch[ORBX_MAX_LEVELS];
     size_t plane[ORBX_MAX_LEVELS];
@@ -58,6 +58,7 @@ struct orbx_ctx {
     // device arenas (grown on demand)
     DevBuf d_pyr, d_blur, d_cand, d_ccount, d_dense_pts, d_dense_node, d_lvl_kps, d_lvl_count;
     DevBuf d_out_kps, d_out_desc, d_out_n;  // results of the host-memory entry points
+    DevBuf d_stamps;                        // diagnostic builds (-DORBX_STAMPS)
 
     // last batch (for read-backs)
     BatchDev B;
@@ -124,16 +125,18 @@ int set_geometry(orbx_ctx* c, int w, int h) {
     }
     std::vector<TileDesc> tiles;
     build_fast_tiles(levels, cells, &tiles);
-    int tile_b = 0, plane_b = 0, queue_b = 0;
+    int tile_b = 0, plane_b = 0, queue_b = 0, kept_b = 0;
     for (const TileDesc& t : tiles) {
         const FastLds need = fast_lds_need(t.wd, t.hd, t.nc);
         tile_b = std::max(tile_b, need.tile);
         plane_b = std::max(plane_b, need.plane);
         queue_b = std::max(queue_b, need.queue);
+        kept_b = std::max(kept_b, need.kept);
     }
+    queue_b = (int)align_up((size_t)queue_b, 16);
     tile_b = (int)align_up((size_t)tile_b, 16);
     plane_b = (int)align_up((size_t)plane_b, 16);
-    const size_t fast_lds = (size_t)tile_b + 2 * (size_t)plane_b + (size_t)queue_b + 16;
+    const size_t fast_lds = (size_t)tile_b + (size_t)plane_b + (size_t)queue_b + (size_t)kept_b + 16;
     if (fast_lds > 160 * 1024 - 256) return ORBX_E_GEOMETRY;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     rc = ensure(c, &c->d_cells, cells.size() * sizeof(CellDesc));
@@ -185,6 +188,7 @@ int set_geometry(orbx_ctx* c, int w, int h) {
     c->tiles.swap(tiles);
     c->fast_tile_bytes = tile_b;
     c->fast_plane_bytes = plane_b;
+    c->fast_queue_bytes = queue_b;
     c->fast_lds = fast_lds;
     c->cell_cap = cell_cap;
     c->total_cells = (int)c->cells.size();
@@ -230,6 +234,9 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     B.kp_total = c->kp_total;
     B.ini_th = c->prm.ini_th_fast;
     B.min_th = c->prm.min_th_fast;
+#ifdef ORBX_STAMPS
+    if (ensure(c, &c->d_stamps, 64 * 8) == ORBX_OK) B.stamps = (unsigned long long*)c->d_stamps.p;
+#endif
     {
         const char* e = getenv("ORBX_DBG");
         B.dbg = e ? atoi(e) : 0;
@@ -290,7 +297,7 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     // stage 1: FAST cells
     hipLaunchKernelGGL(k_fast_tiles, dim3((unsigned)c->tiles.size(), n), dim3(256), c->fast_lds, st, B,
                        (const TileDesc*)c->d_tiles.p, (uint32_t*)c->d_cand.p, (uint32_t*)c->d_ccount.p,
-                       c->fast_tile_bytes, c->fast_plane_bytes);
+                       c->fast_tile_bytes, c->fast_plane_bytes, c->fast_queue_bytes);
     if (prof) HIP_TRY(c, hipEventRecord(c->ev[2], st));
     // stage 2: quadtree retention
     hipLaunchKernelGGL(k_octree, dim3(L, n), dim3(256), c->oct_lds, st, B, (const uint32_t*)c->d_cand.p,
@@ -375,9 +382,16 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->prm.device_id);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+#ifdef ORBX_STAMPS
+    if (c->d_stamps.p) {
+        unsigned long long h[64];
+        if (hipMemcpy(h, c->d_stamps.p, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
+            for (int i = 0; i < 16; ++i) std::fprintf(stderr, "stamp[%d] = %llu\n", i, h[i]);
+    }
+#endif
     DevBuf* bufs[] = {&c->d_cells, &c->d_tiles, &c->d_pat, &c->d_pyr, &c->d_blur, &c->d_cand, &c->d_ccount,
                       &c->d_dense_pts, &c->d_dense_node, &c->d_lvl_kps, &c->d_lvl_count, &c->d_out_kps,
-                      &c->d_out_desc, &c->d_out_n};
+                      &c->d_out_desc, &c->d_out_n, &c->d_stamps};
     for (DevBuf* b : bufs) release(b);
     for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
         release(&c->d_xt[l]);

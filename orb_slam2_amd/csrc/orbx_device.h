@@ -54,6 +54,7 @@ struct BatchDev {
     int32_t dense_total;   // dense candidates per frame over all levels
     int32_t kp_total;      // retained points per frame over all levels (sum of max_kp)
     int32_t ini_th, min_th;
+    unsigned long long* stamps;  // cycle sums per phase, diagnostic builds only (null otherwise)
     int32_t dbg;           // ablation switches for timing experiments (0 in normal operation)
     int32_t blur_first[ORBX_MAX_LEVELS + 1];  // first blur block of each level; [nlevels] = total
 };

@@ -118,6 +118,29 @@ def test_flat_and_sparse_images(oracle):
     ex.close()
 
 
+def test_dense_noise_images(oracle):
+    """Images in which most pixels pass the rejection test: the survivor queue of a tile overflows and
+    the kernel's every-pixel path runs; salt-and-pepper noise puts many pixels on both polarities."""
+    w, h = 400, 300
+    rng = np.random.default_rng(11)
+    white = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    salt = np.full((h, w), 128, np.uint8)
+    m = rng.random((h, w))
+    salt[m < 0.25] = 0
+    salt[m > 0.75] = 255
+    checker = (((np.add.outer(np.arange(h), np.arange(w)) & 1) * 200) + 20).astype(np.uint8)
+    half = white.copy()
+    half[:, w // 2:] = synth.make_frame(w, h, 2, 1)[:, w // 2:]
+    ex = oa.ORBextractor(800, 1.2, 5, 20, 7, max_width=w, max_height=h)
+    orc = oracle.Oracle(800, 1.2, 5, 20, 7)
+    for img in (white, salt, checker, half):
+        kps, desc = ex(img)
+        okps, odesc = orc.extract(img)
+        _check_stages(ex, orc, img)
+        _check_final(kps, desc, okps, odesc)
+    ex.close()
+
+
 def test_errors():
     ex = oa.ORBextractor(500, 1.2, 8, 20, 7, max_width=320, max_height=240)
     with pytest.raises(oa.OrbxError):
