@@ -94,12 +94,12 @@ struct __attribute__((packed, aligned(1))) uint4_unaligned {
 constexpr int kFastStageDepth = 3;  // 16-byte loads in flight per thread while staging a tile
 
 // Diagnostic build only (-DORBX_STAMPS): wave 0 adds the cycles between phase boundaries into
-// B.stamps[phase]; the product build compiles these calls away.
+// B.stamps[phase] (1024 copies, spread by block id, to keep the atomics off one address); the product build compiles these calls away.
 #ifdef ORBX_STAMPS
 #define ORBX_STAMP(B, slot, t0)                                                                   \
     do {                                                                                          \
         const unsigned long long t1_ = __builtin_amdgcn_s_memtime();                               \
-        if (threadIdx.x == 0 && (B).stamps) atomicAdd(&(B).stamps[slot], t1_ - (t0));              \
+        if (threadIdx.x == 0 && (B).stamps) atomicAdd(&(B).stamps[(slot) + 16 * ((blockIdx.x + 37 * blockIdx.y) & 1023)], t1_ - (t0));              \
         (t0) = __builtin_amdgcn_s_memtime();                                                       \
     } while (0)
 #else
@@ -107,7 +107,8 @@ constexpr int kFastStageDepth = 3;  // 16-byte loads in flight per thread while 
 #endif
 
 struct FastShared {  // small per-workgroup state in static LDS
-    int q_front, q_back, n_kept, retry;
+    int q_fb;  // survivors queued so far: front end in the low 16 bits, back end in the high 16
+    int n_kept, retry, pad;
     int kept[kFastTileCells];
     int th[kFastTileCells];
 };
@@ -162,10 +163,7 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
 #ifdef ORBX_STAMPS
     t0 = __builtin_amdgcn_s_memtime();
 #endif
-    if (tid == 0) {
-        sh->q_front = 0;
-        sh->q_back = 0;
-    }
+    if (tid == 0) sh->q_fb = 0;
     __syncthreads();
     // ---- 1. rejection test, four pixels per work item, two pixels per instruction ----
     // Any arc of 9 holds one pixel of each opposite pair, so a corner needs the two compass pairs
@@ -213,27 +211,40 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
             }
         }
         const int e0 = (v << 8) + 4 * j;
-        const uint64_t below = (1ull << lane) - 1ull;
+        // masks of the passing pixels, [side][pixel of the dword]
+        uint64_t m[2][4];
+        bool hit[2][4];
+        int tot[2];
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
             const uint32_t pe = side ? pd[0] : pb[0], po = side ? pd[1] : pb[1];
-            const uint64_t m0 = __ballot((pe & 0x8000u) != 0), m1 = __ballot((po & 0x8000u) != 0),
-                           m2 = __ballot((int)pe < 0), m3 = __ballot((int)po < 0);
-            const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
-            const int tot = n0 + n1 + n2 + n3;
-            if (tot) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(side ? &sh->q_back : &sh->q_front, tot);
-                base = __builtin_amdgcn_readfirstlane(base);
-                // front grows upwards from 0, back grows downwards from q_cap - 1
-                const int sg = side ? -1 : 1, org = side ? q_cap - 1 - base : base;
-                // positions beyond the buffer are dropped; the overflow is detected after the loop
-                const int r0 = __popcll(m0 & below), r1 = n0 + __popcll(m1 & below), r2 = n0 + n1 + __popcll(m2 & below),
-                          r3 = n0 + n1 + n2 + __popcll(m3 & below);
-                if ((pe & 0x8000u) && base + r0 < q_cap) s_queue[org + sg * r0] = (uint16_t)(e0 + 0);
-                if ((po & 0x8000u) && base + r1 < q_cap) s_queue[org + sg * r1] = (uint16_t)(e0 + 1);
-                if ((int)pe < 0 && base + r2 < q_cap) s_queue[org + sg * r2] = (uint16_t)(e0 + 2);
-                if ((int)po < 0 && base + r3 < q_cap) s_queue[org + sg * r3] = (uint16_t)(e0 + 3);
+            hit[side][0] = (pe & 0x8000u) != 0;
+            hit[side][1] = (po & 0x8000u) != 0;
+            hit[side][2] = (int)pe < 0;
+            hit[side][3] = (int)po < 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) m[side][b] = __ballot(hit[side][b]);
+            tot[side] = __popcll(m[side][0]) + __popcll(m[side][1]) + __popcll(m[side][2]) + __popcll(m[side][3]);
+        }
+        if (tot[0] | tot[1]) {
+            // one counter update reserves both ends: front count in the low half, back count in the high half
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&sh->q_fb, tot[0] | (tot[1] << 16));
+            base = __builtin_amdgcn_readfirstlane(base);
+            // a reservation that does not fit is skipped as a whole; the overflow is detected after the loop
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                int at = side ? (int)((uint32_t)base >> 16) : (base & 0xFFFF);
+                if (at + tot[side] > q_cap) continue;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint64_t mm = m[side][b];
+                    if (hit[side][b]) {
+                        const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, (uint32_t)at));
+                        s_queue[side ? q_cap - 1 - r : r] = (uint16_t)(e0 + b);  // front grows up from 0, back down from q_cap - 1
+                    }
+                    at += __popcll(mm);
+                }
             }
         }
         v += dv;
@@ -245,7 +256,7 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
     }
     __syncthreads();
     ORBX_STAMP(B, stamp_base + 0, t0);
-    const int qf = sh->q_front, qb = sh->q_back;
+    const int qf = sh->q_fb & 0xFFFF, qb = (int)((uint32_t)sh->q_fb >> 16);
     if (qf + qb > q_cap) {
         // queue overflow (a tile of dense noise): score every pixel on both sides, no survivors list;
         // the output stage then finds the maxima by scanning the score plane

@@ -235,7 +235,8 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     B.ini_th = c->prm.ini_th_fast;
     B.min_th = c->prm.min_th_fast;
 #ifdef ORBX_STAMPS
-    if (ensure(c, &c->d_stamps, 64 * 8) == ORBX_OK) B.stamps = (unsigned long long*)c->d_stamps.p;
+    if (!c->d_stamps.p && ensure(c, &c->d_stamps, 1024 * 16 * 8) == ORBX_OK) (void)hipMemset(c->d_stamps.p, 0, 1024 * 16 * 8);
+    B.stamps = (unsigned long long*)c->d_stamps.p;
 #endif
     {
         const char* e = getenv("ORBX_DBG");
@@ -384,9 +385,13 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
 #ifdef ORBX_STAMPS
     if (c->d_stamps.p) {
-        unsigned long long h[64];
-        if (hipMemcpy(h, c->d_stamps.p, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
-            for (int i = 0; i < 16; ++i) std::fprintf(stderr, "stamp[%d] = %llu\n", i, h[i]);
+        std::vector<unsigned long long> h(1024 * 16);
+        if (hipMemcpy(h.data(), c->d_stamps.p, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+            for (int i = 0; i < 16; ++i) {
+                unsigned long long sum = 0;
+                for (int k = 0; k < 1024; ++k) sum += h[(size_t)k * 16 + i];
+                std::fprintf(stderr, "stamp[%d] = %llu\n", i, sum);
+            }
     }
 #endif
     DevBuf* bufs[] = {&c->d_cells, &c->d_tiles, &c->d_pat, &c->d_pyr, &c->d_blur, &c->d_cand, &c->d_ccount,
