@@ -25,6 +25,21 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 W, H, NFEAT, NLEVELS, SCALE, INI_TH, MIN_TH = 1241, 376, 2000, 8, 1.2, 20, 7
 PAIRS = 256
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+# HBM bytes per launch from the committed rocprofv3 counter passes of this same command
+# (tools/traffic_pass.sh + tools/traffic_summary.py); counters cannot be read from inside the process.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_traffic.json")
+STAGE_KERNEL = {"pyramid": "k_resize", "fast": "k_fast_tiles", "quadtree": "k_octree", "blur": "k_blur7_all",
+                "orient_describe": "k_orient_describe"}
+
+
+def measured_traffic(stage, frames_per_step):
+    """PMC-measured HBM bytes per launch of the stage's kernel, scaled to this run's batch size."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            t = json.load(f)
+        return t[STAGE_KERNEL[stage]]["traffic_bytes"] * frames_per_step / 512.0
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def level_pixels(oa):
@@ -157,9 +172,10 @@ def main():
             "orient_describe": 1321 * kavg,
         }
         dom = max((k for k in stage_ms if stage_bytes[k] > 0), key=lambda k: stage_ms[k])
-        launches = {"pyramid": NLEVELS - 1, "fast": 1, "quadtree": 1, "blur": NLEVELS, "orient_describe": 1}
-        dom_bytes = stage_bytes[dom] * n  # per stage pass over the batch
-        achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9
+        launches = {"pyramid": NLEVELS - 1, "fast": 1, "quadtree": 1, "blur": 1, "orient_describe": 1}
+        # per launch: algorithmic bytes of the stage / its launches, over the average launch duration
+        dom_bytes = stage_bytes[dom] * n / launches[dom]
+        achieved = dom_bytes / (stage_ms[dom] / launches[dom] * 1e-3) / 1e9
         out = {
             "metric": "ORB frames/sec (1241x376, 2000 kp, 8 lvl)",
             "value": fps,
@@ -186,9 +202,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "algorithmic_bytes_per_step": dom_bytes,
-                "kernel_ms_per_step": stage_ms[dom],
+                "traffic": measured_traffic(dom, n),
+                "algorithmic_bytes_per_launch": dom_bytes,
+                "kernel_ms_per_launch": stage_ms[dom] / launches[dom],
             },
             "path_roofline": {
                 "algorithmic_bytes_per_frame": b_frame,

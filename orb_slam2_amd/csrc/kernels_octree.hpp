@@ -23,6 +23,7 @@
 namespace orbx {
 
 constexpr uint32_t kNoSplit = 0xFFFFFFFFu;
+constexpr int kPtBatch = 8;  // global loads in flight per thread in the loops over the points
 
 // In-place exclusive scan of a[0..n) in LDS by 256 threads; returns the total.
 // Thread t owns the run [t*per, (t+1)*per).
@@ -50,7 +51,7 @@ struct OctLds {
     uint32_t* mid;                    // split point (mx | my << 16) of a node split in this pass, else kNoSplit
     uint32_t* best;                   // final arg-max key per slot
     uint16_t *ordA, *ordB;            // list order, ping-pong
-    uint32_t* key;                    // per order index: point count if expandable else 0
+    uint32_t* key;                    // per order index: count << 16 | (0xFFFF - index) if expandable else 0
     uint16_t* rank;                   // per order index: processing rank among expandable nodes
     uint16_t* proc;                   // processing rank -> order index
     uint32_t* scanA;                  // per rank: created | growth << 16 (then its exclusive scan)
@@ -77,6 +78,10 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
     const int level = blockIdx.x, frame = blockIdx.y;
     const LevelDev& L = B.lv[level];
     const int N = L.quota;
+    unsigned long long t0 = 0;
+#ifdef ORBX_STAMPS
+    t0 = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- prologue: gather the level's candidates into a dense array, in cell order ----------
     uint32_t* s_prefix = reinterpret_cast<uint32_t*>(s_raw);
@@ -93,19 +98,36 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
         return;
     }
     const float h_x = L.h_x;
-    for (int p = tid; p < C; p += 256) {
-        int lo = 0, hi = L.n_cells;  // last cell with prefix <= p
-        while (hi - lo > 1) {
-            const int m = (lo + hi) >> 1;
-            if ((int)s_prefix[m] <= p) lo = m; else hi = m;
+    // Global loads are issued kPtBatch at a time before their first use: the loops over the points
+    // are latency-bound, and independent loads in flight divide the number of round trips.
+    for (int p0 = tid; p0 < C; p0 += 256 * kPtBatch) {
+        uint32_t v[kPtBatch];
+        uint64_t src[kPtBatch];
+#pragma unroll
+        for (int k = 0; k < kPtBatch; ++k) {
+            const int p = min(p0 + 256 * k, C - 1);
+            int lo = 0, hi = L.n_cells;  // last cell with prefix <= p
+            while (hi - lo > 1) {
+                const int m = (lo + hi) >> 1;
+                if ((int)s_prefix[m] <= p) lo = m; else hi = m;
+            }
+            src[k] = (slot0 + lo) * B.cell_cap + (p - (int)s_prefix[lo]);
         }
-        const uint32_t v = cand[(slot0 + lo) * B.cell_cap + (p - (int)s_prefix[lo])];
-        pts[p] = v;
-        int r = (int)((float)pt_x(v) / h_x);  // root of the point (:620)
-        r = min(r, L.n_ini - 1);
-        node_of[p] = (uint16_t)r;
+#pragma unroll
+        for (int k = 0; k < kPtBatch; ++k) v[k] = cand[src[k]];
+#pragma unroll
+        for (int k = 0; k < kPtBatch; ++k) {
+            const int p = p0 + 256 * k;
+            if (p < C) {
+                pts[p] = v[k];
+                int r = (int)((float)pt_x(v[k]) / h_x);  // root of the point (:620)
+                r = min(r, L.n_ini - 1);
+                node_of[p] = (uint16_t)r;
+            }
+        }
     }
     __syncthreads();  // s_prefix is dead from here on; the node tables take its place
+    ORBX_STAMP(B, 8, t0);
 
     // ---- carve the node tables -----------------------------------------------------------------
     OctLds T;
@@ -143,7 +165,14 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
         T.by0[i] = 0;
         T.by1[i] = (uint16_t)L.rect_h;
     }
-    for (int p = tid; p < C; p += 256) atomicAdd(&T.cnt[node_of[p]], 1u);
+    for (int p0 = tid; p0 < C; p0 += 256 * kPtBatch) {
+        int s[kPtBatch];
+#pragma unroll
+        for (int k = 0; k < kPtBatch; ++k) s[k] = p0 + 256 * k < C ? (int)node_of[p0 + 256 * k] : -1;
+#pragma unroll
+        for (int k = 0; k < kPtBatch; ++k)
+            if (s[k] >= 0) atomicAdd(&T.cnt[s[k]], 1u);
+    }
     __syncthreads();
     int n_alive = 0;
     {
@@ -164,25 +193,37 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
     uint16_t* ord_new = T.ordB;
 
     // child-quadrant counts of every node with > 1 point
-    for (int p = tid; p < C; p += 256) {
-        const int s = node_of[p];
-        if (T.cnt[s] > 1) {
-            const uint32_t v = pts[p];
-            const int x0 = T.bx0[s], x1 = T.bx1[s], y0 = T.by0[s], y1 = T.by1[s];
-            const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);  // ceil halves (:512-513)
-            const int q = (pt_x(v) >= mx ? 1 : 0) + (pt_y(v) >= my ? 2 : 0);
-            atomicAdd(&T.cc[4 * s + q], 1u);
+    for (int p0 = tid; p0 < C; p0 += 256 * kPtBatch) {
+        int sn[kPtBatch];
+        uint32_t v[kPtBatch];
+#pragma unroll
+        for (int k = 0; k < kPtBatch; ++k) {
+            const bool ok = p0 + 256 * k < C;
+            sn[k] = ok ? (int)node_of[p0 + 256 * k] : -1;
+            v[k] = ok ? pts[p0 + 256 * k] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kPtBatch; ++k) {
+            const int s = sn[k];
+            if (s >= 0 && T.cnt[s] > 1) {
+                const int x0 = T.bx0[s], x1 = T.bx1[s], y0 = T.by0[s], y1 = T.by1[s];
+                const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);  // ceil halves (:512-513)
+                const int q = (pt_x(v[k]) >= mx ? 1 : 0) + (pt_y(v[k]) >= my ? 2 : 0);
+                atomicAdd(&T.cc[4 * s + q], 1u);
+            }
         }
     }
     __syncthreads();
 
+    ORBX_STAMP(B, 9, t0);
     bool careful = false;
     for (;;) {
         // ---------------- node step ----------------
         const int n = n_alive;
-        for (int i = tid; i < n; i += 256) {
-            const uint32_t c = T.cnt[ord[i]];
-            T.key[i] = c > 1 ? c : 0;
+        // sort key of an expandable node: size, then list position (earlier first); unique, 0 = not expandable
+        for (int i = tid; i < ((n + 3) & ~3); i += 256) {
+            const uint32_t c = i < n ? T.cnt[ord[i]] : 0u;
+            T.key[i] = c > 1 ? (c << 16) | (0xFFFFu - (uint32_t)i) : 0u;
         }
         if (tid == 0) {
             s_i[0] = 0x7FFFFFFF;
@@ -203,9 +244,10 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
                 const uint32_t ki = T.key[i];
                 if (ki) {
                     int r = 0;
-                    for (int j = 0; j < n; ++j) {
-                        const uint32_t kj = T.key[j];
-                        r += (kj > ki || (kj == ki && j < i)) ? 1 : 0;
+                    const uint4* k4 = reinterpret_cast<const uint4*>(T.key);
+                    for (int j = 0; j < (n + 3) >> 2; ++j) {
+                        const uint4 kj = k4[j];
+                        r += (kj.x > ki ? 1 : 0) + (kj.y > ki ? 1 : 0) + (kj.z > ki ? 1 : 0) + (kj.w > ki ? 1 : 0);
                     }
                     T.rank[i] = (uint16_t)r;
                     cnt_exp++;
@@ -316,28 +358,43 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
             ord_new = t;
         }
 
+        ORBX_STAMP(B, careful ? 11 : 10, t0);
         // ---------------- point step ----------------
-        for (int p = tid; p < C; p += 256) {
-            int s = node_of[p];
-            const uint32_t v = pts[p];
-            const uint32_t m = T.mid[s];
-            if (m != kNoSplit) {
-                const int q = (pt_x(v) >= (int)(m & 0xFFFF) ? 1 : 0) + (pt_y(v) >= (int)(m >> 16) ? 2 : 0);
-                s = T.child[4 * s + q];
-                node_of[p] = (uint16_t)s;
-                if (!finished && T.cnt[s] > 1) {
-                    const int x0 = T.bx0[s], x1 = T.bx1[s], y0 = T.by0[s], y1 = T.by1[s];
-                    const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
-                    const int q2 = (pt_x(v) >= mx ? 1 : 0) + (pt_y(v) >= my ? 2 : 0);
-                    atomicAdd(&T.cc[4 * s + q2], 1u);
-                }
+        for (int p0 = tid; p0 < C; p0 += 256 * kPtBatch) {
+            int sn[kPtBatch];
+            uint32_t vv[kPtBatch];
+#pragma unroll
+            for (int k = 0; k < kPtBatch; ++k) {
+                const bool ok = p0 + 256 * k < C;
+                sn[k] = ok ? (int)node_of[p0 + 256 * k] : -1;
+                vv[k] = ok ? pts[p0 + 256 * k] : 0u;
             }
-            if (finished) {
-                // largest response, lowest candidate index on ties (:836-846)
-                atomicMax(&T.best[s], ((uint32_t)pt_score(v) << 24) | (0xFFFFFFu - (uint32_t)p));
+#pragma unroll
+            for (int k = 0; k < kPtBatch; ++k) {
+                int s = sn[k];
+                if (s < 0) continue;
+                const int p = p0 + 256 * k;
+                const uint32_t v = vv[k];
+                const uint32_t m = T.mid[s];
+                if (m != kNoSplit) {
+                    const int q = (pt_x(v) >= (int)(m & 0xFFFF) ? 1 : 0) + (pt_y(v) >= (int)(m >> 16) ? 2 : 0);
+                    s = T.child[4 * s + q];
+                    node_of[p] = (uint16_t)s;
+                    if (!finished && T.cnt[s] > 1) {
+                        const int x0 = T.bx0[s], x1 = T.bx1[s], y0 = T.by0[s], y1 = T.by1[s];
+                        const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+                        const int q2 = (pt_x(v) >= mx ? 1 : 0) + (pt_y(v) >= my ? 2 : 0);
+                        atomicAdd(&T.cc[4 * s + q2], 1u);
+                    }
+                }
+                if (finished) {
+                    // largest response, lowest candidate index on ties (:836-846)
+                    atomicMax(&T.best[s], ((uint32_t)pt_score(v) << 24) | (0xFFFFFFu - (uint32_t)p));
+                }
             }
         }
         __syncthreads();
+        ORBX_STAMP(B, 12, t0);
         if (finished) break;
         for (int s = tid; s < n_slots; s += 256) T.mid[s] = kNoSplit;
         __syncthreads();
@@ -351,6 +408,7 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
         out[i] = pts[p];
     }
     if (tid == 0) *out_count = n_alive;
+    ORBX_STAMP(B, 13, t0);
 }
 
 }  // namespace orbx
