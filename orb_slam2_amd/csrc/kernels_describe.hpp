@@ -76,7 +76,7 @@ __device__ __forceinline__ int wave_sum_to_lane63(int v) {
     return v;
 }
 
-typedef uint32_t desc_u32_unaligned __attribute__((aligned(1)));
+typedef u32_unaligned desc_u32_unaligned;
 
 // One workgroup handles up to kDescKp retained keypoints of one (frame, level) in three phases:
 //  A. orientation moments: each wave takes its keypoints in turn; the 31x31 patch is read as 31
@@ -126,31 +126,29 @@ __global__ __launch_bounds__(256) void k_orient_describe(BatchDev B, const uint3
     // ---- lane constants of phase A: four patch dwords (row, dword-of-row) and their weights ----
     // Row half-widths of the radius-15 disc (reference src/ORBextractor.cc:473-493).
     const int umax_tab[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-    int ic_off[4], ic_v[4];
-    uint32_t ic_wu[4], ic_w1[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int it = lane + 64 * t;         // 0..255, 248 used
-        const int row = it >> 3, dwi = it & 7; // row 0..30 -> v = row-15; dword 0..7 -> u = 4*dwi-15 .. +3
-        const int vv = row - 15;
-        uint32_t wu = 0, w1 = 0;
+    // lane = (row, half): bytes u = -15 + 16*half .. +15 of patch row v = row - 15
+    int ic_off = 0, ic_v = 0;
+    uint32_t ic_wu[4] = {0, 0, 0, 0}, ic_w1[4] = {0, 0, 0, 0};
+    {
+        const int row = lane >> 1, half = lane & 1, vv = row - 15;
         if (row < 31) {
             int um = 0;
 #pragma unroll
             for (int q = 0; q < 16; ++q) um = (abs(vv) == q) ? umax_tab[q] : um;
 #pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-                const int u = 4 * dwi - 15 + bb;
-                if (abs(u) <= um) {
-                    wu |= (uint32_t)(u + 16) << (8 * bb);
-                    w1 |= 1u << (8 * bb);
+            for (int d = 0; d < 4; ++d) {
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int u = 16 * half + 4 * d + bb - 15;
+                    if (abs(u) <= um) {
+                        ic_wu[d] |= (uint32_t)(u + 16) << (8 * bb);
+                        ic_w1[d] |= 1u << (8 * bb);
+                    }
                 }
             }
+            ic_v = vv;
+            ic_off = vv * L.pitch + 16 * half - 15;
         }
-        ic_wu[t] = wu;
-        ic_w1[t] = w1;
-        ic_v[t] = row < 31 ? vv : 0;
-        ic_off[t] = row < 31 ? vv * L.pitch + 4 * dwi - 15 : 0;
     }
     // ---- lane constants of phase C: the eight pattern points of tests 4*lane .. 4*lane+3 ----
     float pat_x[8], pat_y[8];
@@ -172,29 +170,18 @@ __global__ __launch_bounds__(256) void k_orient_describe(BatchDev B, const uint3
         const uint32_t pk = __builtin_amdgcn_readfirstlane(s_pk[kp]);
         return img + (uint64_t)(pt_y(pk) + kBorder) * L.pitch + (pt_x(pk) + kBorder);  // level coordinates (:936-937)
     };
-    uint32_t nx[4];
-    if (cnt > 0) {
-        const uint8_t* c = patch_ptr(kp0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) nx[t] = *reinterpret_cast<const desc_u32_unaligned*>(c + ic_off[t]);
-    }
+    uint4 nx = make_uint4(0, 0, 0, 0);
+    if (cnt > 0) nx = *reinterpret_cast<const uint4_unaligned*>(patch_ptr(kp0) + ic_off);
     for (int q = 0; q < cnt; ++q) {
-        uint32_t px[4];
+        const uint32_t px[4] = {nx.x, nx.y, nx.z, nx.w};
+        if (q + 1 < cnt) nx = *reinterpret_cast<const uint4_unaligned*>(patch_ptr(kp0 + q + 1) + ic_off);
+        int su = 0, s1 = 0;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) px[t] = nx[t];
-        if (q + 1 < cnt) {
-            const uint8_t* c = patch_ptr(kp0 + q + 1);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) nx[t] = *reinterpret_cast<const desc_u32_unaligned*>(c + ic_off[t]);
+        for (int d = 0; d < 4; ++d) {
+            s1 = (int)__builtin_amdgcn_udot4(px[d], ic_w1[d], (uint32_t)s1, false);
+            su = (int)__builtin_amdgcn_udot4(px[d], ic_wu[d], (uint32_t)su, false);
         }
-        int m10 = 0, m01 = 0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int s1 = (int)__builtin_amdgcn_udot4(px[t], ic_w1[t], 0u, false);
-            const int su = (int)__builtin_amdgcn_udot4(px[t], ic_wu[t], 0u, false);
-            m10 += su - 16 * s1;
-            m01 += ic_v[t] * s1;
-        }
+        int m10 = su - 16 * s1, m01 = ic_v * s1;
         m10 = wave_sum_to_lane63(m10);
         m01 = wave_sum_to_lane63(m01);
         if (lane == 63) {

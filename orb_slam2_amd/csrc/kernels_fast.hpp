@@ -86,11 +86,6 @@ __host__ __device__ inline FastLds fast_lds_need(int wd, int hd, int nc) {
     return n;
 }
 
-typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-struct __attribute__((packed, aligned(1))) uint4_unaligned {
-    uint32_t x, y, z, w;
-    __device__ operator uint4() const { return make_uint4(x, y, z, w); }
-};
 constexpr int kFastStageDepth = 3;  // 16-byte loads in flight per thread while staging a tile
 
 // Diagnostic build only (-DORBX_STAMPS): wave 0 adds the cycles between phase boundaries into

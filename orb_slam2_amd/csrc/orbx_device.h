@@ -22,6 +22,13 @@ __host__ __device__ inline int pt_x(uint32_t p) { return (int)(p & 0xFFFu); }
 __host__ __device__ inline int pt_y(uint32_t p) { return (int)((p >> 12) & 0xFFFu); }
 __host__ __device__ inline int pt_score(uint32_t p) { return (int)(p >> 24); }
 
+// Loads at byte-granular addresses: gfx950 global and LDS loads of 4 and 16 bytes need no alignment.
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+struct __attribute__((packed, aligned(1))) uint4_unaligned {
+    uint32_t x, y, z, w;
+    __device__ operator uint4() const { return make_uint4(x, y, z, w); }
+};
+
 // Per-level view used by every kernel.  Images of one level for all frames of the batch are
 // contiguous: frame f of level l starts at img + f*plane, rows `pitch` bytes apart.
 struct LevelDev {
