@@ -18,6 +18,7 @@ CONFIGS = [
     (1241, 376, 2000, 8, 3),
     (752, 480, 1200, 8, 4),
     (317, 211, 500, 6, 7),
+    (3840, 2160, 8000, 12, 5),   # 4K, 12 levels: largest quadtree tables and tile counts
 ]
 
 
