@@ -51,24 +51,30 @@ def level_pixels(oa):
 
 
 def make_frames_gpu(torch, n, rank, stride):
-    """n distinct synthetic frames in HBM: n/8 generated frames x {flips} x {inversion}."""
+    """n synthetic frames in HBM as n/2 stereo pairs (2k, 2k+1).  Left frames: n/8 generated scenes x
+    {vertical flip} x {inversion}; the right frame of a pair is its left frame seen 4..19 px further
+    left (a constant-disparity view, columns beyond the edge repeated), so that the stereo stage after
+    the extractor has real correspondences to find."""
     from orb_slam2_amd import synth
     nbase = (n + 7) // 8
     base = synth.make_batch(nbase, W, H, config_id=3, first_idx=rank * nbase)
     tb = torch.from_numpy(base).cuda()
-    variants = []
+    lefts = []
     for inv in (False, True):
-        for fh in (False, True):
-            for fv in (False, True):
-                t = tb
-                if fh:
-                    t = t.flip(2)
-                if fv:
-                    t = t.flip(1)
-                if inv:
-                    t = 255 - t
-                variants.append(t)
-    allf = torch.stack(variants, 1).reshape(-1, H, W)[:n]  # pair (2k, 2k+1) = flips of one scene
+        for fv in (False, True):
+            t = tb
+            if fv:
+                t = t.flip(1)
+            if inv:
+                t = 255 - t
+            lefts.append(t)
+    left = torch.stack(lefts, 1).reshape(-1, H, W)[:(n + 1) // 2]
+    right = torch.empty_like(left)
+    for k in range(left.shape[0]):
+        d = 4 + (k % 16)
+        right[k, :, :W - d] = left[k, :, d:]
+        right[k, :, W - d:] = left[k, :, W - 1:W]
+    allf = torch.stack([left, right], 1).reshape(-1, H, W)[:n]
     frames = torch.zeros((n, H, stride), dtype=torch.uint8, device="cuda")
     frames[:, :, :W] = allf
     return frames, base
@@ -179,6 +185,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the stage after the extractor (stereo association of the pairs of the batch), timed on its own:
+    # it is not part of `value`
+    d_u = torch.empty((args.pairs, cap), dtype=torch.float32, device="cuda")
+    d_dep = torch.empty((args.pairs, cap), dtype=torch.float32, device="cuda")
+    mb, mbf = 0.5371657, 386.1448  # KITTI 00-02
+    torch.cuda.synchronize()
+
+    def stereo():
+        ex.stereo_match_batch_device(args.pairs, d_kps.data_ptr(), cap, d_desc.data_ptr(), d_n.data_ptr(), mb, mbf,
+                                     d_u.data_ptr(), d_dep.data_ptr(), sync=False)
+
+    stereo()
+    ex.synchronize()
+    ts = time.perf_counter()
+    for _ in range(args.steps):
+        stereo()
+    ex.synchronize()
+    stereo_ms = 1000.0 * (time.perf_counter() - ts) / args.steps
+
     if rank == 0:
         counts = d_n.cpu().numpy()
         kavg = float(counts.mean())
@@ -236,6 +261,9 @@ def main():
                 "frac_of_hbm_peak": b_frame * fps / world / 1e9 / HBM_PEAK_GBS,
             },
             "stage_ms": stage_ms,
+            "next_stage": {"name": "stereo association of the batch's pairs (not part of value)",
+                           "ms_per_step": stereo_ms, "pairs_per_s": args.pairs / (stereo_ms * 1e-3),
+                           "matched_fraction": float((d_u >= 0).float().sum().item() / max(1.0, float(counts[0::2].sum())))},
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(base)

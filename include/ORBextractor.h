@@ -65,6 +65,15 @@ public:
 
     std::vector<cv::Mat> mvImagePyramid;
 
+    // Extension, not in the reference header: the body of Frame::ComputeStereoMatches
+    // (reference src/Frame.cc:485-659) evaluated on the GPU from the pyramids, keypoints and
+    // descriptors this (left) extractor and `right` produced in their last operator() calls.
+    // vuRight / vDepth are the reference's mvuRight / mvDepth (-1 = no match); mb and mbf are the
+    // Frame members of the same names.  With this call in place Frame no longer reads
+    // mvImagePyramid, so the pyramid copy to the host can be switched off (ORBX_KEEP_PYRAMID=0).
+    void ComputeStereoMatches(ORBextractor& right, float mb, float mbf, std::vector<float>& vuRight,
+                              std::vector<float>& vDepth);
+
 protected:
     int nfeatures;
     double scaleFactor;

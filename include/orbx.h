@@ -126,6 +126,31 @@ int orbx_extract_batch_device(orbx_ctx* ctx, int n, const uint8_t* d_imgs, int w
 
 int orbx_synchronize(orbx_ctx* ctx);
 
+/* ---- the stage after the extractor: stereo association ---------------------------------
+ * Replaces Frame::ComputeStereoMatches (reference src/Frame.cc:485-659, descriptor distance
+ * src/ORBmatcher.cc:1684-1700): for every left keypoint the best right keypoint in its row
+ * band by Hamming distance, refined by an 11x11 window distance over 11 shifts on the
+ * keypoint's pyramid level and a parabola fit, then the cut at 1.5*1.4*median.  It reads the
+ * pyramids where the extractions left them in device memory, so in stereo mode no pyramid has
+ * to be copied to the host (the reference reads mvImagePyramid at :492,582,594,599).
+ * mb = stereo baseline in metres, mbf = baseline * fx (src/Frame.cc:114); outputs are the
+ * reference's mvuRight and mvDepth: -1 where a left keypoint has no match. */
+
+/* Left image `img_left` of `left`'s last orbx_extract / orbx_extract_batch against right
+ * image `img_right` of `right`'s (the reference's two extractor instances; both contexts on
+ * one device, same parameters and image size; `left` and `right` may be the same context).
+ * Writes *n_left values to the host arrays u_right and depth (capacity `cap` each). */
+int orbx_stereo_match(orbx_ctx* left, int img_left, orbx_ctx* right, int img_right, float mb,
+                      float mbf, float* u_right, float* depth, int cap, int* n_left);
+
+/* Throughput form, everything in device memory: pair p = images (2p, 2p+1) of ctx's last
+ * orbx_extract_batch_device; d_kps, d_desc, d_n are the arrays that call filled (kp_cap as
+ * passed there, and its level-0 input must still be valid if it was used in place);
+ * d_u_right and d_depth hold n_pairs * kp_cap floats, row p for the left image of pair p. */
+int orbx_stereo_match_batch_device(orbx_ctx* ctx, int n_pairs, const orbx_kp* d_kps, int kp_cap,
+                                   const uint8_t* d_desc, const int32_t* d_n, float mb, float mbf,
+                                   float* d_u_right, float* d_depth, int sync);
+
 /* Copies pyramid level `level` of image `img_idx` of the LAST extraction to host memory
  * (un-padded, rows dst_stride apart).  Replaces reads of the public member mvImagePyramid
  * (reference include/ORBextractor.h:85; read by src/Frame.cc:492,582,594,599). */

@@ -11,6 +11,7 @@
 #include "orb_oracle.h"
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -782,4 +783,169 @@ extern "C" void orc_get_level_padded(const orc_ctx* c, int level, uint8_t* out) 
         uint8_t* D = out + (size_t)(y + E) * pw;
         for (int x = -E; x < w + E; x++) D[x + E] = S[reflect101(x, w)];
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stereo association: Frame::ComputeStereoMatches, reference src/Frame.cc:485-659.
+// ---------------------------------------------------------------------------------------------
+
+// src/ORBmatcher.cc:1684-1700 (the bit trick there is a population count per 32-bit word)
+extern "C" int orc_descriptor_distance(const uint8_t a[32], const uint8_t b[32]) {
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t pa, pb;
+        std::memcpy(&pa, a + 4 * i, 4);
+        std::memcpy(&pb, b + 4 * i, 4);
+        uint32_t v = pa ^ pb;
+        v = v - ((v >> 1) & 0x55555555u);
+        v = (v & 0x33333333u) + ((v >> 2) & 0x33333333u);
+        dist += (int)((((v + (v >> 4)) & 0xF0F0F0Fu) * 0x1010101u) >> 24);
+    }
+    return dist;
+}
+
+// Pixel of mvImagePyramid[level] at ROI coordinates that may lie in the 19-px border
+// (the border holds the reflect-101 continuation, src/ORBextractor.cc:1239-1245).
+static inline int pyr_px(const orc_ctx* c, int level, int x, int y) {
+    return c->level[level][(size_t)reflect101(y, c->h[level]) * c->w[level] + reflect101(x, c->w[level])];
+}
+
+extern "C" int orc_stereo_match(const orc_ctx* left, const orc_ctx* right, float mb, float mbf,
+                                float* u_right, float* depth, int32_t* sad) {
+    const int TH_HIGH = 100, TH_LOW = 50;  // src/ORBmatcher.cc:37-38
+    const int N = (int)left->kps.size();
+    for (int i = 0; i < N; i++) {  // :487-488
+        u_right[i] = -1.0f;
+        depth[i] = -1.0f;
+        if (sad) sad[i] = -1;
+    }
+    if (N == 0 || left->h[0] <= 0) return 0;
+    const float* scale = left->p.scale;
+    const float* inv_scale = left->p.inv_scale;
+    const int thOrbDist = (TH_HIGH + TH_LOW) / 2;  // :490
+    const int nRows = left->h[0];                  // :492
+
+    // :494-512 right keypoints by image row
+    std::vector<std::vector<size_t> > vRowIndices(nRows);
+    const int Nr = (int)right->kps.size();
+    for (int iR = 0; iR < Nr; iR++) {
+        const orc_kp& kp = right->kps[iR];
+        const float kpY = kp.y;
+        const float r = 2.0f * scale[kp.octave];
+        const int maxr = (int)std::ceil(kpY + r);
+        const int minr = (int)std::floor(kpY - r);
+        for (int yi = minr; yi <= maxr; yi++)
+            if (yi >= 0 && yi < nRows) vRowIndices[yi].push_back((size_t)iR);  // D7
+    }
+
+    // :514-517
+    const float minZ = mb;
+    const float minD = 0;
+    const float maxD = mbf / minZ;
+
+    std::vector<std::pair<int, int> > vDistIdx;
+    vDistIdx.reserve(N);
+    for (int iL = 0; iL < N; iL++) {
+        const orc_kp& kpL = left->kps[iL];
+        const int levelL = kpL.octave;
+        const float vL = kpL.y;
+        const float uL = kpL.x;
+        const size_t row = (size_t)vL;  // :530 (float index, truncated)
+        if (row >= (size_t)nRows) continue;
+        const std::vector<size_t>& vCandidates = vRowIndices[row];
+        if (vCandidates.empty()) continue;
+        const float minU = uL - maxD;
+        const float maxU = uL - minD;
+        if (maxU < 0) continue;
+
+        int bestDist = TH_HIGH;
+        size_t bestIdxR = 0;
+        const uint8_t* dL = &left->desc[(size_t)iL * 32];
+        for (size_t iC = 0; iC < vCandidates.size(); iC++) {  // :547-568
+            const size_t iR = vCandidates[iC];
+            const orc_kp& kpR = right->kps[iR];
+            if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+            const float uR = kpR.x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = orc_descriptor_distance(dL, &right->desc[iR * 32]);
+                if (dist < bestDist) {
+                    bestDist = dist;
+                    bestIdxR = iR;
+                }
+            }
+        }
+
+        if (bestDist < thOrbDist) {  // :571
+            const float uR0 = right->kps[bestIdxR].x;
+            const float scaleFactor = inv_scale[kpL.octave];
+            const float scaleduL = roundf(kpL.x * scaleFactor);
+            const float scaledvL = roundf(kpL.y * scaleFactor);
+            const float scaleduR0 = roundf(uR0 * scaleFactor);
+            const int w = 5;
+            const int lv = kpL.octave;
+            const int xL = (int)(scaleduL - w), yL = (int)(scaledvL - w);  // window origin, :582
+            const int cL = pyr_px(left, lv, xL + w, yL + w);                // IL.at(w,w), :584
+
+            int bestDistW = INT_MAX;
+            int bestincR = 0;
+            const int L = 5;
+            float vDists[2 * 5 + 1];
+            const float iniu = scaleduR0 + L - w;
+            const float endu = scaleduR0 + L + w + 1;
+            if (iniu < 0 || endu >= right->w[lv]) continue;  // :594
+
+            for (int incR = -L; incR <= +L; incR++) {  // :597-611
+                const int xR = (int)(scaleduR0 + incR - w);
+                const int cR = pyr_px(right, lv, xR + w, yL + w);
+                // cv::norm(IL, IR, NORM_L1) of the two centred float windows: integers, exact
+                double acc = 0.0;
+                for (int yy = 0; yy < 2 * w + 1; yy++)
+                    for (int xx = 0; xx < 2 * w + 1; xx++) {
+                        const float a = (float)pyr_px(left, lv, xL + xx, yL + yy) - (float)cL;
+                        const float b = (float)pyr_px(right, lv, xR + xx, yL + yy) - (float)cR;
+                        acc += (double)std::fabs(a - b);
+                    }
+                const float dist = (float)acc;
+                if (dist < bestDistW) {
+                    bestDistW = (int)dist;
+                    bestincR = incR;
+                }
+                vDists[L + incR] = dist;
+            }
+            if (bestincR == -L || bestincR == L) continue;  // :613
+
+            // :616-624 parabola through the three distances around the minimum
+            const float dist1 = vDists[L + bestincR - 1];
+            const float dist2 = vDists[L + bestincR];
+            const float dist3 = vDists[L + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (deltaR < -1 || deltaR > 1) continue;
+
+            float bestuR = scale[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);  // :627
+            float disparity = (uL - bestuR);
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) {  // :633-637, double constants
+                    disparity = (float)0.01;
+                    bestuR = (float)((double)uL - 0.01);
+                }
+                depth[iL] = mbf / disparity;
+                u_right[iL] = bestuR;
+                if (sad) sad[iL] = bestDistW;
+                vDistIdx.push_back(std::pair<int, int>(bestDistW, iL));
+            }
+        }
+    }
+
+    if (vDistIdx.empty()) return 0;  // D7
+    std::sort(vDistIdx.begin(), vDistIdx.end());  // :645
+    const float median = (float)vDistIdx[vDistIdx.size() / 2].first;
+    const float thDist = 1.5f * 1.4f * median;
+    int kept = (int)vDistIdx.size();
+    for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {  // :649-658
+        if (vDistIdx[i].first < thDist) break;
+        u_right[vDistIdx[i].second] = -1;
+        depth[vDistIdx[i].second] = -1;
+        kept--;
+    }
+    return kept;
 }

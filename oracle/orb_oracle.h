@@ -20,6 +20,11 @@
  *       sequence: among equal sizes the most recently created node is split first.
  *   D3  fastAtan2 polynomial in IEEE float32, separate multiply and add.
  *   D5  Gaussian taps 18,34,49,55,49,34,18 (sum 257, OpenCV 3.4.5 fixed-point path).
+ *   D7  stereo matching (src/Frame.cc:485-659): float32 statements evaluated as written, no
+ *       contraction across statements (bestuR = scale*(...) is rounded before uL - bestuR);
+ *       an empty match list leaves every output at -1 (the reference indexes an empty
+ *       vector at :646); right keypoints whose row band leaves [0, rows) only fill the rows
+ *       that exist (the reference writes out of bounds at :511).
  *   D6  a = cos, b = sin of the float32 radian angle are float32 roundings of a
  *       double-precision evaluation (fixed range reduction + fdlibm kernels, explicit
  *       fma) -- the correctly rounded value on every input checked.
@@ -103,6 +108,19 @@ void orc_get_candidates(const orc_ctx* c, int level, orc_cand* out);
 int orc_get_num_level_keypoints(const orc_ctx* c, int level);
 /* 19-pixel reflect-101 padded level as ComputePyramid builds it: (w+38)*(h+38) */
 void orc_get_level_padded(const orc_ctx* c, int level, uint8_t* out);
+
+
+/* ---- next stage after the extractor: stereo association ---------------------------------- */
+/* ORBmatcher::DescriptorDistance (reference src/ORBmatcher.cc:1684-1700): Hamming distance of
+   two 32-byte descriptors. */
+int orc_descriptor_distance(const uint8_t a[32], const uint8_t b[32]);
+/* Frame::ComputeStereoMatches (reference src/Frame.cc:485-659) on the keypoints, descriptors and
+   pyramids left by the last orc_extract of `left` and `right` (same extractor parameters).
+   mb = baseline in metres, mbf = baseline * fx (src/Frame.cc:114).  u_right, depth: one value
+   per left keypoint, -1 where there is no match.  sad (may be null): the window distance of
+   each accepted match before the median cut, -1 elsewhere.  Returns the matches kept. */
+int orc_stereo_match(const orc_ctx* left, const orc_ctx* right, float mb, float mbf,
+                     float* u_right, float* depth, int32_t* sad);
 
 #ifdef __cplusplus
 }

@@ -47,6 +47,7 @@ EXPORTS = [
     "orbx_create", "orbx_destroy", "orbx_extract", "orbx_extract_batch", "orbx_extract_batch_device",
     "orbx_synchronize", "orbx_pyramid_level", "orbx_debug_read", "orbx_set_profiling", "orbx_get_stage_ms",
     "orbx_stage_name", "orbx_strerror", "orbx_last_hip_error", "orbx_version",
+    "orbx_stereo_match", "orbx_stereo_match_batch_device",
 ]
 
 _lib = None
@@ -73,6 +74,8 @@ def load_library():
     L.orbx_extract_batch.argtypes = [vp, i32, vp, i32, i32, vp, vp, i32, vp, vp]
     L.orbx_extract_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, vp, i32, vp, vp, i32]
     L.orbx_synchronize.argtypes = [vp]
+    L.orbx_stereo_match.argtypes = [vp, i32, vp, i32, f32, f32, vp, vp, i32, C.POINTER(i32)]
+    L.orbx_stereo_match_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, f32, f32, vp, vp, i32]
     L.orbx_pyramid_level.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.orbx_debug_read.argtypes = [vp, i32, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.orbx_set_profiling.argtypes = [vp, i32]
@@ -252,6 +255,26 @@ class ORBextractor:
 
     def synchronize(self):
         _check(self._L.orbx_synchronize(self._ctx), self._ctx)
+
+    # ---- the stage after the extractor: Frame::ComputeStereoMatches (src/Frame.cc:485-659) ----
+    def stereo_match(self, right, mb, mbf, img_left=0, img_right=0):
+        """Associates image `img_left` of this extractor's last host-memory extraction with image
+        `img_right` of `right`'s (another ORBextractor, or this one).  Returns (mvuRight, mvDepth):
+        float32 arrays with one value per left keypoint, -1 where there is no match."""
+        cap = self.max_keypoints(*self._last_size())
+        u = np.empty(cap, np.float32)
+        d = np.empty(cap, np.float32)
+        n = C.c_int(0)
+        _check(self._L.orbx_stereo_match(self._ctx, img_left, right._ctx, img_right, mb, mbf, _ptr(u), _ptr(d), cap,
+                                         C.byref(n)), self._ctx)
+        return u[:n.value].copy(), d[:n.value].copy()
+
+    def stereo_match_batch_device(self, n_pairs, d_kps, kp_cap, d_desc, d_n, mb, mbf, d_u_right, d_depth, sync=True):
+        """Pairs (2p, 2p+1) of the last extract_batch_device; raw device addresses (ints); see
+        orbx_stereo_match_batch_device."""
+        _check(self._L.orbx_stereo_match_batch_device(self._ctx, n_pairs, C.c_void_p(d_kps), kp_cap, C.c_void_p(d_desc),
+                                                      C.c_void_p(d_n), mb, mbf, C.c_void_p(d_u_right),
+                                                      C.c_void_p(d_depth), int(sync)), self._ctx)
 
     # ---- pyramid read-back: the public member mvImagePyramid (include/ORBextractor.h:85) ----
     def pyramid_level(self, img_idx, level, padded=False):

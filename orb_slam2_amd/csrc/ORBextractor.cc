@@ -164,4 +164,18 @@ void ExtractorNode::DivideNode(ExtractorNode& n1, ExtractorNode& n2, ExtractorNo
         if (child[q]->vKeys.size() == 1) child[q]->bNoMore = true;
 }
 
+void ORBextractor::ComputeStereoMatches(ORBextractor& right, float mb, float mbf, std::vector<float>& vuRight,
+                                        std::vector<float>& vDepth) {
+    if (!mpCtx || !right.mpCtx) Fatal("ComputeStereoMatches before operator()", ORBX_E_STATE, mpCtx);
+    const int cap = orbx_host_max_keypoints(nfeatures, (float)scaleFactor, nlevels, mnCtxWidth, mnCtxHeight);
+    if (cap < 0) Fatal("orbx_host_max_keypoints", cap, mpCtx);
+    vuRight.assign((size_t)cap, -1.0f);
+    vDepth.assign((size_t)cap, -1.0f);
+    int n = 0;
+    const int rc = orbx_stereo_match(mpCtx, 0, right.mpCtx, 0, mb, mbf, &vuRight[0], &vDepth[0], cap, &n);
+    if (rc != ORBX_OK) Fatal("orbx_stereo_match", rc, mpCtx);
+    vuRight.resize((size_t)n);
+    vDepth.resize((size_t)n);
+}
+
 }  // namespace ORB_SLAM2

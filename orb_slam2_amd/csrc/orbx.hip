@@ -13,6 +13,7 @@
 #include "kernels_fast.hpp"
 #include "kernels_octree.hpp"
 #include "kernels_pyramid.hpp"
+#include "kernels_stereo.hpp"
 #include "orbx_device.h"
 #include "orbx_host.h"
 
@@ -60,9 +61,15 @@ struct orbx_ctx {
     DevBuf d_out_kps, d_out_desc, d_out_n;  // results of the host-memory entry points
     DevBuf d_stamps;                        // diagnostic builds (-DORBX_STAMPS)
 
-    // last batch (for read-backs)
+    // last batch (for read-backs and for the stereo stage)
     BatchDev B;
     bool have_last = false;
+    const orbx_kp* last_kps = nullptr;   // where the last extraction left its results (device)
+    const uint8_t* last_desc = nullptr;
+    const int32_t* last_n = nullptr;
+    int last_kp_cap = 0;
+    // stereo stage scratch (grown on demand)
+    DevBuf d_st_rows, d_st_meta, d_st_wmax, d_st_sad, d_st_u, d_st_depth;
 
     bool profiling = false;
     hipEvent_t ev[ORBX_NUM_STAGES + 1];
@@ -322,6 +329,70 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     }
     HIP_TRY(c, hipGetLastError());
     c->have_last = true;
+    c->last_kps = d_kps;
+    c->last_desc = d_desc;
+    c->last_n = d_n_out;
+    c->last_kp_cap = kp_cap;
+    return ORBX_OK;
+}
+
+// Enqueues the stereo stage for n_pairs pairs on `l`'s stream.  Left images are first_l + p*step of
+// `l`'s last batch, right images first_r + p*step of `r`'s; keypoints/descriptors/counts of pair p
+// are at kps_x + p*kp_step (descriptors 32 bytes each, counts at n_x[p*n_step]).
+int run_stereo(orbx_ctx* l, orbx_ctx* r, int n_pairs, int first_l, int first_r, int step, const orbx_kp* kps_l,
+               const orbx_kp* kps_r, const uint8_t* desc_l, const uint8_t* desc_r, const int32_t* n_l,
+               const int32_t* n_r, int64_t kp_step, int n_step, int kp_cap, float mb, float mbf, float* d_u_right,
+               float* d_depth) {
+    const BatchDev& BL = l->B;
+    const BatchDev& BR = r->B;
+    const int L = BL.nlevels;
+    StereoDev S;
+    std::memset(&S, 0, sizeof(S));
+    for (int i = 0; i < L; ++i) {
+        S.img_l[i] = BL.lv[i].img;
+        S.img_r[i] = BR.lv[i].img;
+        S.plane_l[i] = BL.lv[i].plane;
+        S.plane_r[i] = BR.lv[i].plane;
+        S.pitch_l[i] = BL.lv[i].pitch;
+        S.pitch_r[i] = BR.lv[i].pitch;
+        S.w[i] = BL.lv[i].w;
+        S.h[i] = BL.lv[i].h;
+        S.scale[i] = l->tab.scale[i];
+        S.inv_scale[i] = l->tab.inv_scale[i];
+    }
+    S.nlevels = L;
+    S.first_l = first_l;
+    S.first_r = first_r;
+    S.step = step;
+    S.kps_l = kps_l;
+    S.kps_r = kps_r;
+    S.desc_l = desc_l;
+    S.desc_r = desc_r;
+    S.n_l = n_l;
+    S.n_r = n_r;
+    S.kp_step = kp_step;
+    S.n_step = n_step;
+    S.kp_cap = kp_cap;
+    S.rows = BL.lv[0].h;
+    S.max_d = mbf / mb;  // :517, float division
+    S.mbf = mbf;
+    int rc;
+    if ((rc = ensure(l, &l->d_st_rows, (size_t)n_pairs * (S.rows + 1) * 4))) return rc;
+    if ((rc = ensure(l, &l->d_st_meta, (size_t)n_pairs * kp_cap * sizeof(StereoMeta)))) return rc;
+    if ((rc = ensure(l, &l->d_st_wmax, (size_t)n_pairs * 4))) return rc;
+    if ((rc = ensure(l, &l->d_st_sad, (size_t)n_pairs * kp_cap * 4))) return rc;
+    S.row_start = (uint32_t*)l->d_st_rows.p;
+    S.meta = (StereoMeta*)l->d_st_meta.p;
+    S.wmax = (int32_t*)l->d_st_wmax.p;
+    S.sad = (int32_t*)l->d_st_sad.p;
+    S.u_right = d_u_right;
+    S.depth = d_depth;
+    hipStream_t st = l->stream;
+    hipLaunchKernelGGL(k_stereo_rows, dim3(n_pairs), dim3(256), (size_t)(S.rows + 1) * 4, st, S);
+    hipLaunchKernelGGL(k_stereo_search, dim3((kp_cap + kStereoKpPerBlock - 1) / kStereoKpPerBlock, n_pairs), dim3(256), 0,
+                       st, S);
+    hipLaunchKernelGGL(k_stereo_cut, dim3(n_pairs), dim3(1024), (size_t)((kp_cap + 3) & ~3) * 4, st, S);
+    HIP_TRY(l, hipGetLastError());
     return ORBX_OK;
 }
 
@@ -396,7 +467,8 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
 #endif
     DevBuf* bufs[] = {&c->d_cells, &c->d_tiles, &c->d_pat, &c->d_pyr, &c->d_blur, &c->d_cand, &c->d_ccount,
                       &c->d_dense_pts, &c->d_dense_node, &c->d_lvl_kps, &c->d_lvl_count, &c->d_out_kps,
-                      &c->d_out_desc, &c->d_out_n, &c->d_stamps};
+                      &c->d_out_desc, &c->d_out_n, &c->d_stamps, &c->d_st_rows, &c->d_st_meta, &c->d_st_wmax,
+                      &c->d_st_sad, &c->d_st_u, &c->d_st_depth};
     for (DevBuf* b : bufs) release(b);
     for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
         release(&c->d_xt[l]);
@@ -470,6 +542,57 @@ extern "C" int orbx_extract(orbx_ctx* c, const uint8_t* img, int width, int heig
     const uint8_t* imgs[1] = {img};
     int strides[1] = {stride};
     return orbx_extract_batch(c, 1, imgs, width, height, strides, kps, kp_cap, desc, n_out);
+}
+
+extern "C" int orbx_stereo_match_batch_device(orbx_ctx* c, int n_pairs, const orbx_kp* d_kps, int kp_cap,
+                                              const uint8_t* d_desc, const int32_t* d_n, float mb, float mbf,
+                                              float* d_u_right, float* d_depth, int sync) {
+    if (!c || !d_kps || !d_desc || !d_n || !d_u_right || !d_depth || n_pairs < 1 || kp_cap < 1) return ORBX_E_INVALID;
+    if (!(mb > 0.0f) || !(mbf > 0.0f)) return ORBX_E_INVALID;
+    if (!c->have_last) return ORBX_E_STATE;
+    if (2 * n_pairs > c->B.nframes || kp_cap > 65535) return ORBX_E_CAPACITY;
+    HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    // pair p = images (2p, 2p + 1) of the last batch; their results are 2 * kp_cap keypoints apart
+    int rc = run_stereo(c, c, n_pairs, 0, 1, 2, d_kps, d_kps + kp_cap, d_desc, d_desc + (size_t)kp_cap * 32, d_n, d_n + 1,
+                        2 * (int64_t)kp_cap, 2, kp_cap, mb, mbf, d_u_right, d_depth);
+    if (rc) return rc;
+    if (sync) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_stereo_match(orbx_ctx* left, int img_left, orbx_ctx* right, int img_right, float mb, float mbf,
+                                 float* u_right, float* depth, int cap, int* n_left) {
+    if (!left || !right || !u_right || !depth || !n_left) return ORBX_E_INVALID;
+    if (!(mb > 0.0f) || !(mbf > 0.0f)) return ORBX_E_INVALID;
+    if (!left->have_last || !right->have_last || !left->last_kps || !right->last_kps) return ORBX_E_STATE;
+    if (img_left < 0 || img_left >= left->B.nframes || img_right < 0 || img_right >= right->B.nframes) return ORBX_E_INVALID;
+    if (left->prm.device_id != right->prm.device_id) return ORBX_E_INVALID;
+    // both extractions must share the extractor parameters and the image size
+    if (left->B.nlevels != right->B.nlevels || left->cur_w != right->cur_w || left->cur_h != right->cur_h ||
+        left->prm.scale_factor != right->prm.scale_factor || left->last_kp_cap != right->last_kp_cap)
+        return ORBX_E_INVALID;
+    HIP_TRY(left, hipSetDevice(left->prm.device_id));
+    HIP_TRY(left, hipStreamSynchronize(right->stream));  // the right extraction has finished
+    const int kp_cap = left->last_kp_cap;
+    if (kp_cap > 65535) return ORBX_E_CAPACITY;
+    int32_t nl = 0;
+    HIP_TRY(left, hipMemcpyAsync(&nl, left->last_n + img_left, 4, hipMemcpyDeviceToHost, left->stream));
+    int rc;
+    if ((rc = ensure(left, &left->d_st_u, (size_t)kp_cap * 4))) return rc;
+    if ((rc = ensure(left, &left->d_st_depth, (size_t)kp_cap * 4))) return rc;
+    rc = run_stereo(left, right, 1, img_left, img_right, 0, left->last_kps + (size_t)img_left * kp_cap,
+                    right->last_kps + (size_t)img_right * kp_cap, left->last_desc + (size_t)img_left * kp_cap * 32,
+                    right->last_desc + (size_t)img_right * kp_cap * 32, left->last_n + img_left, right->last_n + img_right, 0,
+                    0, kp_cap, mb, mbf, (float*)left->d_st_u.p, (float*)left->d_st_depth.p);
+    if (rc) return rc;
+    HIP_TRY(left, hipStreamSynchronize(left->stream));
+    *n_left = nl;
+    if (nl > cap) return ORBX_E_CAPACITY;
+    if (nl > 0) {
+        HIP_TRY(left, hipMemcpy(u_right, left->d_st_u.p, (size_t)nl * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(left, hipMemcpy(depth, left->d_st_depth.p, (size_t)nl * 4, hipMemcpyDeviceToHost));
+    }
+    return ORBX_OK;
 }
 
 extern "C" int orbx_synchronize(orbx_ctx* c) {

@@ -1,7 +1,9 @@
 // Test harness for the drop-in C++ class (include/ORBextractor.h).
 //   harness tables <nfeatures> <scale> <nlevels>                 -> prints the getter tables
 //   harness extract <nf> <scale> <nl> <ini> <min> <w> <h> <stride> <in.raw> <out.bin>
-// out.bin: int32 K, K*28 bytes keypoints (cv::KeyPoint field order), K*32 bytes descriptors,
+//   harness stereo <nf> <scale> <nl> <w> <h> <left.raw> <right.raw> <mb> <mbf> <out.bin>
+//       out.bin: int32 N, N floats mvuRight, N floats mvDepth
+// extract's out.bin: int32 K, K*28 bytes keypoints (cv::KeyPoint field order), K*32 bytes descriptors,
 // then per level: int32 w, int32 h, (w+38)*(h+38) bytes of the padded pyramid buffer.
 #include <cstdio>
 #include <cstdlib>
@@ -52,6 +54,39 @@ int main(int argc, char** argv) {
             std::fwrite(dims, 4, 2, o);
             const unsigned char* base = roi.data - 19 * roi.step - 19;
             for (int y = 0; y < roi.rows + 38; y++) std::fwrite(base + (size_t)y * roi.step, 1, roi.cols + 38, o);
+        }
+        std::fclose(o);
+        return 0;
+    }
+    if (argc >= 12 && !std::strcmp(argv[1], "stereo")) {
+        const int nf = std::atoi(argv[2]), nl = std::atoi(argv[4]);
+        const float sc = (float)std::atof(argv[3]);
+        const int w = std::atoi(argv[5]), h = std::atoi(argv[6]);
+        std::vector<unsigned char> rawl((size_t)w * h), rawr((size_t)w * h);
+        FILE* fl = std::fopen(argv[7], "rb");
+        FILE* fr = std::fopen(argv[8], "rb");
+        if (!fl || !fr || std::fread(&rawl[0], 1, rawl.size(), fl) != rawl.size() ||
+            std::fread(&rawr[0], 1, rawr.size(), fr) != rawr.size())
+            return 2;
+        std::fclose(fl);
+        std::fclose(fr);
+        cv::Mat iml(h, w, CV_8UC1, &rawl[0], (size_t)w), imr(h, w, CV_8UC1, &rawr[0], (size_t)w);
+        // two instances, as Tracking constructs them (reference src/Tracking.cc:121-125)
+        ORB_SLAM2::ORBextractor left(nf, sc, nl, 20, 7), right(nf, sc, nl, 20, 7);
+        std::vector<cv::KeyPoint> kl, kr;
+        cv::Mat dl, dr;
+        left(iml, cv::Mat(), kl, dl);
+        right(imr, cv::Mat(), kr, dr);
+        std::vector<float> u, d;
+        left.ComputeStereoMatches(right, (float)std::atof(argv[9]), (float)std::atof(argv[10]), u, d);
+        if (u.size() != kl.size() || d.size() != kl.size()) return 5;
+        FILE* o = std::fopen(argv[11], "wb");
+        if (!o) return 4;
+        int N = (int)u.size();
+        std::fwrite(&N, 4, 1, o);
+        if (N) {
+            std::fwrite(&u[0], 4, (size_t)N, o);
+            std::fwrite(&d[0], 4, (size_t)N, o);
         }
         std::fclose(o);
         return 0;

@@ -83,6 +83,8 @@ def lib():
         L.orc_get_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_get_num_level_keypoints.argtypes = [C.c_void_p, C.c_int]
         L.orc_get_level_padded.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         _ = u8p
         _lib = L
     return _lib
@@ -171,6 +173,24 @@ def descriptor(blurred, x, y, angle):
 def pattern():
     p = lib().orc_pattern()
     return np.ctypeslib.as_array(p, shape=(1024,)).copy()
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    assert a.size == 32 and b.size == 32
+    return int(lib().orc_descriptor_distance(_ptr(a), _ptr(b)))
+
+
+def stereo_match(left, right, mb, mbf):
+    """Frame::ComputeStereoMatches on the last extraction of two Oracle instances.
+    Returns (u_right, depth, sad, kept)."""
+    n = lib().orc_num_keypoints(left._c)
+    u = np.zeros(n, np.float32)
+    d = np.zeros(n, np.float32)
+    sad = np.zeros(n, np.int32)
+    kept = lib().orc_stereo_match(left._c, right._c, mb, mbf, _ptr(u), _ptr(d), _ptr(sad))
+    return u, d, sad, kept
 
 
 class Oracle:

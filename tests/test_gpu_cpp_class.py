@@ -46,3 +46,31 @@ def test_cpp_class_matches_oracle(oracle, tmp_path):
         off += padded.size
         assert (padded == orc.padded_level(l)).all(), "mvImagePyramid level %d" % l
     assert off == len(blob)
+
+
+def test_cpp_stereo_extension_matches_oracle(oracle, tmp_path):
+    """ORBextractor::ComputeStereoMatches (the GPU body of Frame::ComputeStereoMatches, reference
+    src/Frame.cc:485-659) through two class instances, against the CPU oracle, bit-exact."""
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")])
+    w, h, nf, nl, s = 752, 480, 1200, 8, 6
+    wide = synth.make_frame(w + 32, h, 4, 11)
+    left = np.ascontiguousarray(wide[:, :w])
+    right = np.clip(wide[:, s:w + s].astype(np.int32) + np.random.default_rng(3).integers(-3, 4, (h, w)), 0, 255)
+    right = np.ascontiguousarray(right.astype(np.uint8))
+    fl, fr, out = tmp_path / "l.raw", tmp_path / "r.raw", tmp_path / "st.bin"
+    left.tofile(fl)
+    right.tofile(fr)
+    mb, mbf = 0.11, 47.9
+    subprocess.check_call([EXE, "stereo", str(nf), "1.2", str(nl), str(w), str(h), str(fl), str(fr), repr(mb), repr(mbf),
+                           str(out)], timeout=120)
+    blob = out.read_bytes()
+    n = int(np.frombuffer(blob, np.int32, 1)[0])
+    u = np.frombuffer(blob, np.uint32, n, 4)
+    d = np.frombuffer(blob, np.uint32, n, 4 + 4 * n)
+    ol, orr = oracle.Oracle(nf, 1.2, nl, 20, 7), oracle.Oracle(nf, 1.2, nl, 20, 7)
+    kl, _ = ol.extract(left)
+    orr.extract(right)
+    ou, od, _, kept = oracle.stereo_match(ol, orr, np.float32(mb), np.float32(mbf))
+    assert n == len(kl) and kept > 100
+    assert (u == ou.view(np.uint32)).all() and (d == od.view(np.uint32)).all()
