@@ -142,6 +142,47 @@ def test_dense_noise_images(oracle):
     ex.close()
 
 
+def test_full_size_batch_properties(oracle):
+    """The benchmark configuration itself: 512 KITTI-shape frames in one batch through the
+    device-pointer entry point.  Size-independent properties: a second run reproduces every output
+    byte; frames that are copies of each other give identical results wherever they sit in the
+    batch; sampled frames equal the oracle bit for bit; counts respect nfeatures and the capacity."""
+    from hip_rt import DeviceArray
+    w, h, nf, nl, n = 1241, 376, 2000, 8, 512
+    stride = 1280
+    base = synth.make_batch(16, w, h, 3, 100)
+    host = np.zeros((n, h, stride), np.uint8)
+    for i in range(n):
+        host[i, :, :w] = base[i % 16] if i < 480 else 255 - base[i % 16]
+    frames = DeviceArray.from_host(host)
+    ex = oa.ORBextractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=n, keep_pyramid=False)
+    cap = ex.max_keypoints(w, h)
+    outs = []
+    for rep in range(2):
+        d_kps = DeviceArray((n, cap, 28), np.uint8, fill_byte=0)
+        d_desc = DeviceArray((n, cap, 32), np.uint8, fill_byte=0)
+        d_n = DeviceArray((n,), np.int32, fill_byte=0)
+        ex.extract_batch_device(frames.ptr, n, w, h, stride, h * stride, d_kps.ptr, cap, d_desc.ptr, d_n.ptr, sync=True)
+        outs.append((d_kps.to_host(), d_desc.to_host(), d_n.to_host()))
+        for a in (d_kps, d_desc, d_n):
+            a.free()
+    (k0, q0, c0), (k1, q1, c1) = outs
+    assert (c0 == c1).all() and (c0 >= nf).all() and (c0 <= cap).all()
+    valid = np.arange(cap)[None, :] < c0[:, None]
+    assert (k0[valid] == k1[valid]).all() and (q0[valid] == q1[valid]).all()        # reproducible
+    for i in (16, 33, 250, 479):                                                    # copies agree
+        j = i % 16
+        assert c0[i] == c0[j]
+        assert (k0[i, :c0[i]] == k0[j, :c0[j]]).all() and (q0[i, :c0[i]] == q0[j, :c0[j]]).all()
+    orc = oracle.Oracle(nf, 1.2, nl, 20, 7)
+    for i in (0, 7, 481, 511):                                                      # oracle parity
+        okps, odesc = orc.extract(host[i, :, :w])
+        assert c0[i] == len(okps)
+        _check_final(np.ascontiguousarray(k0[i, :c0[i]]).reshape(-1).view(oa.KP_DTYPE), q0[i, :c0[i]], okps, odesc)
+    ex.close()
+    frames.free()
+
+
 def test_errors():
     ex = oa.ORBextractor(500, 1.2, 8, 20, 7, max_width=320, max_height=240)
     with pytest.raises(oa.OrbxError):
