@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -68,6 +69,10 @@ struct orbx_ctx {
     const uint8_t* last_desc = nullptr;
     const int32_t* last_n = nullptr;
     int last_kp_cap = 0;
+    // pinned host staging for the host-memory entry points (pageable 2-D copies are done row by
+    // row by the runtime and cost milliseconds; one contiguous copy from pinned memory does not)
+    void* h_stage = nullptr;
+    size_t h_stage_bytes = 0;
     // stereo stage scratch (grown on demand)
     DevBuf d_st_rows, d_st_meta, d_st_wmax, d_st_sad, d_st_u, d_st_depth;
 
@@ -206,6 +211,42 @@ int set_geometry(orbx_ctx* c, int w, int h) {
     c->cur_w = w;
     c->cur_h = h;
     c->have_last = false;
+    return ORBX_OK;
+}
+
+constexpr size_t kStageMax = (size_t)64 << 20;  // staging chunk for uploads
+
+int ensure_stage(orbx_ctx* c, size_t bytes) {
+    if (bytes <= c->h_stage_bytes) return ORBX_OK;
+    if (c->h_stage) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipHostFree(c->h_stage));
+        c->h_stage = nullptr;
+        c->h_stage_bytes = 0;
+    }
+    HIP_TRY(c, hipHostMalloc(&c->h_stage, bytes, hipHostMallocDefault));
+    c->h_stage_bytes = bytes;
+    return ORBX_OK;
+}
+
+// Host images -> level 0 of the pyramid arena (device pitch), through the pinned staging buffer.
+int upload_level0(orbx_ctx* c, int n, const uint8_t* const* imgs, const int* strides, int width, int height) {
+    const size_t plane = c->plane[0];
+    const int pitch = c->pitch[0];
+    const int per_chunk = (int)std::max<size_t>(1, kStageMax / plane);
+    int rc = ensure_stage(c, plane * (size_t)std::min(n, per_chunk));
+    if (rc) return rc;
+    for (int i0 = 0; i0 < n; i0 += per_chunk) {
+        const int m = std::min(per_chunk, n - i0);
+        if (i0 > 0) HIP_TRY(c, hipStreamSynchronize(c->stream));  // the previous chunk has left the staging buffer
+        for (int i = 0; i < m; ++i) {
+            uint8_t* d = (uint8_t*)c->h_stage + (size_t)i * plane;
+            const uint8_t* s = imgs[i0 + i];
+            for (int y = 0; y < height; ++y) std::memcpy(d + (size_t)y * pitch, s + (size_t)y * strides[i0 + i], (size_t)width);
+        }
+        HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->d_pyr.p + (size_t)i0 * plane, c->h_stage, (size_t)m * plane,
+                                  hipMemcpyHostToDevice, c->stream));
+    }
     return ORBX_OK;
 }
 
@@ -470,6 +511,7 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
                       &c->d_out_desc, &c->d_out_n, &c->d_stamps, &c->d_st_rows, &c->d_st_meta, &c->d_st_wmax,
                       &c->d_st_sad, &c->d_st_u, &c->d_st_depth};
     for (DevBuf* b : bufs) release(b);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
         release(&c->d_xt[l]);
         release(&c->d_yt[l]);
@@ -509,20 +551,24 @@ extern "C" int orbx_extract_batch(orbx_ctx* c, int n, const uint8_t* const* imgs
     if (rc) return rc;
     for (int i = 0; i < n; ++i)
         if (!imgs[i] || strides[i] < width) return ORBX_E_INVALID;
+    const bool trace = std::getenv("ORBX_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_a = now();
     if ((rc = ensure_arenas(c, n, true))) return rc;
     const int cap = max_keypoints(c->levels);
     if ((rc = ensure(c, &c->d_out_kps, (size_t)n * cap * sizeof(orbx_kp)))) return rc;
     if ((rc = ensure(c, &c->d_out_desc, (size_t)n * cap * 32))) return rc;
     if ((rc = ensure(c, &c->d_out_n, (size_t)n * 4))) return rc;
-    for (int i = 0; i < n; ++i)
-        HIP_TRY(c, hipMemcpy2DAsync((uint8_t*)c->d_pyr.p + (size_t)i * c->plane[0], c->pitch[0], imgs[i], strides[i],
-                                    width, height, hipMemcpyHostToDevice, c->stream));
+    if ((rc = upload_level0(c, n, imgs, strides, width, height))) return rc;
+    const double t_b = now();
     rc = run_batch(c, n, nullptr, 0, 0, (orbx_kp*)c->d_out_kps.p, cap, (uint8_t*)c->d_out_desc.p,
                    (int32_t*)c->d_out_n.p);
     if (rc) return rc;
+    const double t_c = now();
     std::vector<int32_t> cnt(n);
     HIP_TRY(c, hipMemcpyAsync(cnt.data(), c->d_out_n.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const double t_d = now();
     for (int i = 0; i < n; ++i) {
         const int k = cnt[i];
         n_out[i] = k;
@@ -534,6 +580,9 @@ extern "C" int orbx_extract_batch(orbx_ctx* c, int n, const uint8_t* const* imgs
         }
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (trace)
+        std::fprintf(stderr, "orbx_extract_batch host ms: upload-enqueue %.3f launch %.3f wait+counts %.3f download %.3f\n",
+                     t_b - t_a, t_c - t_b, t_d - t_c, now() - t_d);
     return ORBX_OK;
 }
 
@@ -610,7 +659,14 @@ extern "C" int orbx_pyramid_level(orbx_ctx* c, int img_idx, int level, uint8_t* 
     if (dst_stride < D.w) return ORBX_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->prm.device_id));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy2D(dst, dst_stride, D.img + (size_t)img_idx * D.plane, D.pitch, D.w, D.h, hipMemcpyDeviceToHost));
+    // one contiguous copy into pinned memory, rows re-pitched on the host
+    const size_t bytes = (size_t)(D.h - 1) * D.pitch + D.w;
+    int rc = ensure_stage(c, bytes);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->h_stage, D.img + (size_t)img_idx * D.plane, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int y = 0; y < D.h; ++y)
+        std::memcpy(dst + (size_t)y * dst_stride, (const uint8_t*)c->h_stage + (size_t)y * D.pitch, (size_t)D.w);
     if (width) *width = D.w;
     if (height) *height = D.h;
     return ORBX_OK;
