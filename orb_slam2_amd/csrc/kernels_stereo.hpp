@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_stereo_search(StereoDev S) {
                     const bool inside = xl >= 0 && xl + 12 <= lw && xr >= 0 && xr + 12 <= lw && yl >= 0 && yl + 11 <= lh;
                     if (inside) {
                         const int cl = IL[(int64_t)(yl + 5) * pl + xl + 5], cr = IR[(int64_t)(yl + 5) * pr + xr + 5];
-                        const uint32_t off_l = 512u, off_r = (uint32_t)(512 + cl - cr);
+                        const int dc = cl - cr;
                         for (int r = g; r < 11; r += 5) {
                             const uint8_t* rl = IL + (int64_t)(yl + r) * pl + xl;
                             const uint8_t* rr = IR + (int64_t)(yl + r) * pr + xr;
@@ -215,10 +215,12 @@ __global__ __launch_bounds__(256) void k_stereo_search(StereoDev S) {
                             }
 #pragma unroll
                             for (int xx = 0; xx < 11; ++xx) {
-                                const uint32_t pa = (a[xx >> 2] >> (8 * (xx & 3))) & 0xFFu;
-                                const uint32_t pb = (b[xx >> 2] >> (8 * (xx & 3))) & 0xFFu;
-                                // |(pa - cl) - (pb - cr)| on non-negative operands
-                                acc = __sad(pa + off_l, pb + off_r, acc);
+                                const int pa = (int)((a[xx >> 2] >> (8 * (xx & 3))) & 0xFFu);
+                                const int pb = (int)((b[xx >> 2] >> (8 * (xx & 3))) & 0xFFu);
+                                // |(pa - cl) - (pb - cr)|; v_sad_u32 would do it in one instruction but issues
+                                // at a quarter of the rate of sub/max
+                                const int t = pa - pb - dc;
+                                acc += (uint32_t)max(t, -t);
                             }
                         }
                     } else {

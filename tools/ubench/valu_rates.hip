@@ -4,6 +4,8 @@
 #include <cstdio>
 #include <cstdint>
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(uint32_t* out, int iters, uint32_t seed) {
@@ -24,6 +26,14 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, int iters, uint32_t seed
             if (OP == 8) a[i] = min((a[i] >> 16) & 0xFFFF, b);                        // sdwa candidate
             if (OP == 9) a[i] = __builtin_amdgcn_update_dpp(a[i], b + a[i], 0x138, 0xF, 0xF, false);
             if (OP == 10) a[i] = (uint32_t)max((int)a[i] - (int)(b & 0xFF), (int)a[(i + 1) & 7]);
+            if (OP == 11) a[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a[i]), __builtin_bit_cast(u16x2, b)));  // v_pk_max_u16
+            if (OP == 12) a[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(i16x2, a[i]), __builtin_bit_cast(i16x2, b)));  // v_pk_min_i16
+            if (OP == 13) a[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, a[i]) - __builtin_bit_cast(i16x2, b));                          // v_pk_sub_i16
+            if (OP == 14) a[i] = __sad(a[i], b, a[i]);                                                                                                  // v_sad_u32
+            if (OP == 15) a[i] = max(a[i], b);                                                                                                          // v_max_u32
+            if (OP == 16) a[i] = __popc(a[i]) + b;                                                                                                      // v_bcnt_u32_b32
+            if (OP == 17) a[i] = (a[i] >> 8) & 0xFFu;                                                                                                   // v_bfe_u32
+            if (OP == 18) a[i] = (a[i] << 16) | b;                                                                                                      // v_lshl_or_b32
         }
     }
     uint32_t s = 0;
@@ -55,7 +65,7 @@ void run(const char* name, uint32_t* d, int blocks_per_cu) {
 int main() {
     uint32_t* d;
     hipMalloc(&d, 256 * 8 * 256 * 4);
-    for (int bpc : {1, 2, 4, 8}) {
+    for (int bpc : {2, 8}) {
         run<0>("v_add_u32", d, bpc);
         run<1>("v_dot4_u32_u8", d, bpc);
         run<2>("v_dot2_u32_u16", d, bpc);
@@ -67,6 +77,14 @@ int main() {
         run<8>("shift+and+min", d, bpc);
         run<9>("add + mov_dpp", d, bpc);
         run<10>("and,sub,max", d, bpc);
+        run<11>("v_pk_max_u16", d, bpc);
+        run<12>("v_pk_min_i16", d, bpc);
+        run<13>("v_pk_sub_i16", d, bpc);
+        run<14>("v_sad_u32", d, bpc);
+        run<15>("v_max_u32", d, bpc);
+        run<16>("v_bcnt_u32_b32", d, bpc);
+        run<17>("v_bfe_u32", d, bpc);
+        run<18>("v_lshl_or_b32", d, bpc);
     }
     return 0;
 }
