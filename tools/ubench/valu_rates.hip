@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, int iters, uint32_t seed
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            if (OP == 0) a[i] = a[i] + b;                                            // v_add_u32
+            if (OP == 0) a[i] = a[i] + a[(i + 1) & 7];                               // v_add_u32 (not foldable over iterations)
             if (OP == 1) a[i] = __builtin_amdgcn_udot4(a[i], b, a[i], false);        // v_dot4_u32_u8
             if (OP == 2) a[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a[i]), __builtin_bit_cast(u16x2, b), a[i], false);
             if (OP == 3) a[i] = __umul24(a[i], b) + a[i];                            // v_mad_u32_u24
