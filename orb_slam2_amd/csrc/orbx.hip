@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "kernels_describe.hpp"
@@ -73,6 +74,14 @@ struct orbx_ctx {
     // row by the runtime and cost milliseconds; one contiguous copy from pinned memory does not)
     void* h_stage = nullptr;
     size_t h_stage_bytes = 0;
+    // pipelined host batches: two upload slots and two result slots in pinned memory, a stream per
+    // copy direction, events chaining upload -> compute -> download per slot
+    void* h_up[2] = {nullptr, nullptr};
+    void* h_res[2] = {nullptr, nullptr};
+    size_t h_up_bytes = 0, h_res_bytes = 0;
+    hipStream_t st_up = nullptr, st_down = nullptr;
+    hipEvent_t ev_up[2], ev_done[2], ev_down[2];
+    bool pipe_made = false;
     // stereo stage scratch (grown on demand)
     DevBuf d_st_rows, d_st_meta, d_st_wmax, d_st_sad, d_st_u, d_st_depth;
 
@@ -268,9 +277,9 @@ int ensure_arenas(orbx_ctx* c, int n, bool need_level0) {
     return ORBX_OK;
 }
 
-// Enqueues the whole path for n frames whose level 0 is at (l0, l0_pitch, l0_plane) in device memory.
-int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_plane, orbx_kp* d_kps, int kp_cap,
-              uint8_t* d_desc, int32_t* d_n_out) {
+// Describes n frames in c->B: frames frame0 .. frame0+n-1 of arenas laid out for n_total frames
+// (level-major), level 0 at (l0, l0_pitch, l0_plane) when given, else in the pyramid arena too.
+void fill_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_plane, int n_total, int frame0) {
     const int L = c->tab.nlevels;
     BatchDev& B = c->B;
     std::memset(&B, 0, sizeof(B));
@@ -301,15 +310,15 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
             D.pitch = l0_pitch;
             D.plane = l0_plane;
         } else {
-            D.img = (const uint8_t*)c->d_pyr.p + poff;
+            D.img = (const uint8_t*)c->d_pyr.p + poff + c->plane[l] * (size_t)frame0;
             D.pitch = c->pitch[l];
             D.plane = c->plane[l];
-            poff += c->plane[l] * n;
+            poff += c->plane[l] * n_total;
         }
-        D.blur = (uint8_t*)c->d_blur.p + boff;
+        D.blur = (uint8_t*)c->d_blur.p + boff + c->plane[l] * (size_t)frame0;
         D.bpitch = c->pitch[l];
         D.bplane = c->plane[l];
-        boff += c->plane[l] * n;
+        boff += c->plane[l] * n_total;
         D.w = g.w;
         D.h = g.h;
         D.n_cells = g.n_cells;
@@ -329,6 +338,14 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
         kp_off += g.max_kp;
         B.blur_first[l + 1] = B.blur_first[l] + blur_main_blocks(g.w, g.h) + blur_edge_blocks(g.h);
     }
+}
+
+// Enqueues the whole path for n frames (see fill_batch) on the context's stream.
+int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_plane, orbx_kp* d_kps, int kp_cap,
+              uint8_t* d_desc, int32_t* d_n_out, int n_total = -1, int frame0 = 0) {
+    fill_batch(c, n, l0, l0_pitch, l0_plane, n_total < 0 ? n : n_total, frame0);
+    const int L = c->tab.nlevels;
+    BatchDev& B = c->B;
     hipStream_t st = c->stream;
     const bool prof = c->profiling;
     if (prof) HIP_TRY(c, hipEventRecord(c->ev[0], st));
@@ -437,6 +454,127 @@ int run_stereo(orbx_ctx* l, orbx_ctx* r, int n_pairs, int first_l, int first_r, 
     return ORBX_OK;
 }
 
+// Runs fn(i) for i in [0, n) on up to `threads` host threads (the calling thread is one of them).
+template <class F>
+void parallel_for(int n, int threads, F fn) {
+    threads = std::max(1, std::min(threads, n));
+    if (threads == 1) {
+        for (int i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t)
+        pool.emplace_back([=] {
+            for (int i = t; i < n; i += threads) fn(i);
+        });
+    for (int i = 0; i < n; i += threads) fn(i);
+    for (std::thread& th : pool) th.join();
+}
+
+constexpr int kPipeMinFrames = 16;            // smaller batches take the single-shot path
+constexpr size_t kPipeChunkBytes = (size_t)24 << 20;  // level-0 bytes per chunk
+
+int ensure_pipeline(orbx_ctx* c, size_t up_bytes, size_t res_bytes) {
+    if (!c->pipe_made) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->st_up, hipStreamNonBlocking));
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->st_down, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_down[i], hipEventDisableTiming));
+        }
+        c->pipe_made = true;
+    }
+    if (up_bytes > c->h_up_bytes) {
+        for (int i = 0; i < 2; ++i) {
+            if (c->h_up[i]) HIP_TRY(c, hipHostFree(c->h_up[i]));
+            c->h_up[i] = nullptr;
+            HIP_TRY(c, hipHostMalloc(&c->h_up[i], up_bytes, hipHostMallocDefault));
+        }
+        c->h_up_bytes = up_bytes;
+    }
+    if (res_bytes > c->h_res_bytes) {
+        for (int i = 0; i < 2; ++i) {
+            if (c->h_res[i]) HIP_TRY(c, hipHostFree(c->h_res[i]));
+            c->h_res[i] = nullptr;
+            HIP_TRY(c, hipHostMalloc(&c->h_res[i], res_bytes, hipHostMallocDefault));
+        }
+        c->h_res_bytes = res_bytes;
+    }
+    return ORBX_OK;
+}
+
+// Host batch in chunks: while chunk k is extracted on the compute stream, chunk k+1 is staged and
+// uploaded and the results of chunk k-1 are downloaded and handed to the caller.  The device
+// arenas hold the whole batch (pyramids of every frame stay readable afterwards).
+int extract_batch_pipelined(orbx_ctx* c, int n, const uint8_t* const* imgs, int width, int height, const int* strides,
+                            orbx_kp* kps, int kp_cap, uint8_t* desc, int* n_out, int cap) {
+    const size_t plane = c->plane[0];
+    const int pitch = c->pitch[0];
+    int m = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, kPipeChunkBytes / plane));
+    if (const char* e = std::getenv("ORBX_PIPE_CHUNK")) m = std::max(1, std::min(n, std::atoi(e)));  // frames per chunk (tests)
+    const size_t res_kps = (size_t)m * cap * sizeof(orbx_kp), res_desc = (size_t)m * cap * 32, res_cnt = (size_t)m * 4;
+    int rc = ensure_pipeline(c, (size_t)m * plane, res_kps + res_desc + res_cnt);
+    if (rc) return rc;
+    const int host_threads = (int)std::max(1u, std::min(4u, std::thread::hardware_concurrency()));
+    const int nchunks = (n + m - 1) / m;
+    orbx_kp* d_kps = (orbx_kp*)c->d_out_kps.p;
+    uint8_t* d_desc = (uint8_t*)c->d_out_desc.p;
+    int32_t* d_cnt = (int32_t*)c->d_out_n.p;
+
+    auto consume = [&](int k) -> int {  // results of chunk k: pinned slot -> the caller's arrays
+        const int slot = k & 1, f0 = k * m, mk = std::min(m, n - f0);
+        HIP_TRY(c, hipEventSynchronize(c->ev_down[slot]));
+        const uint8_t* base = (const uint8_t*)c->h_res[slot];
+        const int32_t* cnt = (const int32_t*)(base + res_kps + res_desc);
+        parallel_for(mk, host_threads, [&](int i) {
+            const int kk = std::min(cnt[i], kp_cap);
+            n_out[f0 + i] = kk;
+            if (kk > 0) {
+                std::memcpy(kps + (size_t)(f0 + i) * kp_cap, base + (size_t)i * cap * sizeof(orbx_kp), (size_t)kk * sizeof(orbx_kp));
+                std::memcpy(desc + (size_t)(f0 + i) * kp_cap * 32, base + res_kps + (size_t)i * cap * 32, (size_t)kk * 32);
+            }
+        });
+        return ORBX_OK;
+    };
+
+    for (int k = 0; k < nchunks; ++k) {
+        const int slot = k & 1, f0 = k * m, mk = std::min(m, n - f0);
+        if (k >= 2) HIP_TRY(c, hipEventSynchronize(c->ev_up[slot]));  // upload slot free again
+        uint8_t* up = (uint8_t*)c->h_up[slot];
+        parallel_for(mk, host_threads, [&](int i) {
+            uint8_t* d = up + (size_t)i * plane;
+            const uint8_t* s = imgs[f0 + i];
+            const int st = strides[f0 + i];
+            for (int y = 0; y < height; ++y) std::memcpy(d + (size_t)y * pitch, s + (size_t)y * st, (size_t)width);
+        });
+        HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->d_pyr.p + (size_t)f0 * plane, up, (size_t)mk * plane, hipMemcpyHostToDevice,
+                                  c->st_up));
+        HIP_TRY(c, hipEventRecord(c->ev_up[slot], c->st_up));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_up[slot], 0));
+        rc = run_batch(c, mk, nullptr, 0, 0, d_kps + (size_t)f0 * cap, cap, d_desc + (size_t)f0 * cap * 32, d_cnt + f0, n, f0);
+        if (rc) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev_done[slot], c->stream));
+        // the result slot of chunk k-2 was consumed before chunk k-1 was enqueued (below)
+        HIP_TRY(c, hipStreamWaitEvent(c->st_down, c->ev_done[slot], 0));
+        uint8_t* res = (uint8_t*)c->h_res[slot];
+        HIP_TRY(c, hipMemcpyAsync(res, d_kps + (size_t)f0 * cap, (size_t)mk * cap * sizeof(orbx_kp), hipMemcpyDeviceToHost,
+                                  c->st_down));
+        HIP_TRY(c, hipMemcpyAsync(res + res_kps, d_desc + (size_t)f0 * cap * 32, (size_t)mk * cap * 32, hipMemcpyDeviceToHost,
+                                  c->st_down));
+        HIP_TRY(c, hipMemcpyAsync(res + res_kps + res_desc, d_cnt + f0, (size_t)mk * 4, hipMemcpyDeviceToHost, c->st_down));
+        HIP_TRY(c, hipEventRecord(c->ev_down[slot], c->st_down));
+        if (k >= 1 && (rc = consume(k - 1))) return rc;
+    }
+    if ((rc = consume(nchunks - 1))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    fill_batch(c, n, nullptr, 0, 0, n, 0);  // read-backs and the stereo stage see the whole batch
+    c->last_kps = d_kps;
+    c->last_desc = d_desc;
+    c->last_n = d_cnt;
+    return ORBX_OK;
+}
+
 int check_call(orbx_ctx* c, int n, int w, int h, int kp_cap) {
     if (!c || n < 1 || w < 1 || h < 1) return ORBX_E_INVALID;
     if (n > c->prm.max_batch || n > 65535) return ORBX_E_CAPACITY;
@@ -512,6 +650,19 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
                       &c->d_st_sad, &c->d_st_u, &c->d_st_depth};
     for (DevBuf* b : bufs) release(b);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (int i = 0; i < 2; ++i) {
+        if (c->h_up[i]) (void)hipHostFree(c->h_up[i]);
+        if (c->h_res[i]) (void)hipHostFree(c->h_res[i]);
+    }
+    if (c->pipe_made) {
+        for (int i = 0; i < 2; ++i) {
+            (void)hipEventDestroy(c->ev_up[i]);
+            (void)hipEventDestroy(c->ev_done[i]);
+            (void)hipEventDestroy(c->ev_down[i]);
+        }
+        (void)hipStreamDestroy(c->st_up);
+        (void)hipStreamDestroy(c->st_down);
+    }
     for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
         release(&c->d_xt[l]);
         release(&c->d_yt[l]);
@@ -559,6 +710,11 @@ extern "C" int orbx_extract_batch(orbx_ctx* c, int n, const uint8_t* const* imgs
     if ((rc = ensure(c, &c->d_out_kps, (size_t)n * cap * sizeof(orbx_kp)))) return rc;
     if ((rc = ensure(c, &c->d_out_desc, (size_t)n * cap * 32))) return rc;
     if ((rc = ensure(c, &c->d_out_n, (size_t)n * 4))) return rc;
+    if (n >= kPipeMinFrames) {
+        rc = extract_batch_pipelined(c, n, imgs, width, height, strides, kps, kp_cap, desc, n_out, cap);
+        if (trace) std::fprintf(stderr, "orbx_extract_batch (pipelined) host ms: %.3f\n", now() - t_a);
+        return rc;
+    }
     if ((rc = upload_level0(c, n, imgs, strides, width, height))) return rc;
     const double t_b = now();
     rc = run_batch(c, n, nullptr, 0, 0, (orbx_kp*)c->d_out_kps.p, cap, (uint8_t*)c->d_out_desc.p,

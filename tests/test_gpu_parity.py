@@ -83,6 +83,34 @@ def test_batch_matches_per_frame(oracle):
     ex.close()
 
 
+def test_pipelined_host_batch(oracle, monkeypatch):
+    """Host batches of 16 frames or more are processed in chunks with uploads, extraction and downloads
+    overlapped; here 40 frames in chunks of 7.  Results, pyramid read-back and the stereo stage must
+    not depend on the chunking."""
+    monkeypatch.setenv("ORBX_PIPE_CHUNK", "7")
+    w, h, nf, nl, n = 640, 480, 1000, 8, 40
+    base = synth.make_batch(5, w, h, 1, 40)
+    imgs = [np.ascontiguousarray(base[i % 5] if i % 2 == 0 else np.roll(base[i % 5], -(3 + i % 7), axis=1)) for i in range(n)]
+    ex = oa.ORBextractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=n)
+    res = ex.extract_batch(imgs)
+    orc = oracle.Oracle(nf, 1.2, nl, 20, 7)
+    for i in range(n):                                 # every chunk, including the short last one
+        okps, odesc = orc.extract(imgs[i])
+        _check_final(res[i][0], res[i][1], okps, odesc)
+    orc.extract(imgs[9])                               # pyramid of a frame of the second chunk
+    for l in range(nl):
+        assert (ex.pyramid_level(9, l) == orc.level(l)).all()
+    # stereo association between two frames of different chunks of the same context
+    orr = oracle.Oracle(nf, 1.2, nl, 20, 7)
+    orr.extract(imgs[33])                              # the scene of frame 8, shifted by 8 px
+    orc.extract(imgs[8])
+    u, d = ex.stereo_match(ex, 0.11, 47.9, img_left=8, img_right=33)
+    ou, od, osad, _ = oracle.stereo_match(orc, orr, 0.11, 47.9)
+    assert (osad >= 0).sum() > 50
+    assert (u.view(np.uint32) == ou.view(np.uint32)).all() and (d.view(np.uint32) == od.view(np.uint32)).all()
+    ex.close()
+
+
 def test_strided_input_and_reuse(oracle):
     w, h = 640, 480
     big = np.zeros((h, w + 37), np.uint8)
