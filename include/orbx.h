@@ -126,6 +126,29 @@ int orbx_extract_batch_device(orbx_ctx* ctx, int n, const uint8_t* d_imgs, int w
 
 int orbx_synchronize(orbx_ctx* ctx);
 
+/* ---- the stage before the extractor: input staging in device memory ---------------------
+ * Both calls work on n equally sized frames (frame i at base + i*frame_stride, rows `stride`
+ * bytes apart), enqueue on the context's stream and so order themselves before a following
+ * orbx_extract_batch_device on the same context. */
+
+/* Replaces cv::cvtColor(im, im, CV_{RGB,BGR,RGBA,BGRA}2GRAY) of Tracking::GrabImageStereo /
+ * GrabImageRGBD / GrabImageMonocular (reference src/Tracking.cc:175-199, 213-231, 250-268):
+ * OpenCV 3.4.5's 8-bit form (B*1868 + G*9617 + R*4899 + 8192) >> 14.  channels = 3 or 4 (alpha
+ * ignored); blue_idx = 0 for BGR(A) byte order, 2 for RGB(A) (the reference's mbRGB). */
+int orbx_gray_batch_device(orbx_ctx* ctx, int n, const uint8_t* d_src, int width, int height,
+                           int src_stride, size_t src_frame_stride, int channels, int blue_idx,
+                           uint8_t* d_dst, int dst_stride, size_t dst_frame_stride, int sync);
+
+/* Replaces cv::remap(im, imRect, M1, M2, cv::INTER_LINEAR) of the stereo examples (reference
+ * Examples/Stereo/stereo_euroc.cc:137-138; maps from cv::initUndistortRectifyMap, :98-99, stay
+ * a host-side set-up step): 8UC1 image, CV_32FC1 maps of dst_width x dst_height floats (rows
+ * map_stride floats apart, shared by all frames), constant border 0, OpenCV 3.4.5's fixed-point
+ * form (coordinates rounded to 1/32 px, 15-bit weights). */
+int orbx_remap_batch_device(orbx_ctx* ctx, int n, const uint8_t* d_src, int src_width, int src_height,
+                            int src_stride, size_t src_frame_stride, const float* d_mapx,
+                            const float* d_mapy, int map_stride, uint8_t* d_dst, int dst_width,
+                            int dst_height, int dst_stride, size_t dst_frame_stride, int sync);
+
 /* ---- the stage after the extractor: stereo association ---------------------------------
  * Replaces Frame::ComputeStereoMatches (reference src/Frame.cc:485-659, descriptor distance
  * src/ORBmatcher.cc:1684-1700): for every left keypoint the best right keypoint in its row

@@ -949,3 +949,63 @@ extern "C" int orc_stereo_match(const orc_ctx* left, const orc_ctx* right, float
     }
     return kept;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Input staging: gray conversion and rectification (reference src/Tracking.cc:175-199,
+// Examples/Stereo/stereo_euroc.cc:137-138), OpenCV 3.4.5 8-bit paths.
+// ---------------------------------------------------------------------------------------------
+
+extern "C" void orc_cvt_gray(const uint8_t* src, int w, int h, int sstride, int channels, int blue_idx,
+                             uint8_t* dst, int dstride) {
+    // RGB2Gray<uchar>: table form of (b*B2Y + g*G2Y + r*R2Y + (1 << 13)) >> 14
+    const int B2Y = 1868, G2Y = 9617, R2Y = 4899, shift = 14;
+    for (int y = 0; y < h; y++) {
+        const uint8_t* S = src + (size_t)y * sstride;
+        uint8_t* D = dst + (size_t)y * dstride;
+        for (int x = 0; x < w; x++, S += channels) {
+            const int b = S[blue_idx], g = S[1], r = S[blue_idx ^ 2];
+            D[x] = (uint8_t)((b * B2Y + g * G2Y + r * R2Y + (1 << (shift - 1))) >> shift);
+        }
+    }
+}
+
+static inline int sat_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+
+extern "C" void orc_remap_linear(const uint8_t* src, int sw, int sh, int sstride, const float* mapx,
+                                 const float* mapy, int map_stride, uint8_t* dst, int dw, int dh, int dstride) {
+    const int INTER_BITS = 5, INTER_TAB_SIZE = 1 << INTER_BITS;
+    for (int y = 0; y < dh; y++) {
+        const float* MX = mapx + (size_t)y * map_stride;
+        const float* MY = mapy + (size_t)y * map_stride;
+        uint8_t* D = dst + (size_t)y * dstride;
+        for (int x = 0; x < dw; x++) {
+            // remap(): float maps -> fixed point, 5 fractional bits
+            const int fsx = cv_round((double)(MX[x] * (float)INTER_TAB_SIZE));
+            const int fsy = cv_round((double)(MY[x] * (float)INTER_TAB_SIZE));
+            const int sx = sat_short(fsx >> INTER_BITS), sy = sat_short(fsy >> INTER_BITS);
+            const int fx = fsx & (INTER_TAB_SIZE - 1), fy = fsy & (INTER_TAB_SIZE - 1);
+            // BilinearTab_i: exact for bilinear weights, sum 32768
+            const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32;
+            const int w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+            int v;
+            if ((unsigned)sx < (unsigned)(sw - 1) && (unsigned)sy < (unsigned)(sh - 1)) {
+                const uint8_t* S = src + (size_t)sy * sstride + sx;
+                v = S[0] * w00 + S[1] * w01 + S[sstride] * w10 + S[sstride + 1] * w11;
+            } else if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) {
+                D[x] = 0;  // BORDER_CONSTANT, borderValue 0
+                continue;
+            } else {
+                const int sx1 = sx + 1, sy1 = sy + 1;
+                const bool x0 = (unsigned)sx < (unsigned)sw, x1 = (unsigned)sx1 < (unsigned)sw;
+                const bool y0 = (unsigned)sy < (unsigned)sh, y1 = (unsigned)sy1 < (unsigned)sh;
+                const int v0 = (x0 && y0) ? src[(size_t)sy * sstride + sx] : 0;
+                const int v1 = (x1 && y0) ? src[(size_t)sy * sstride + sx1] : 0;
+                const int v2 = (x0 && y1) ? src[(size_t)sy1 * sstride + sx] : 0;
+                const int v3 = (x1 && y1) ? src[(size_t)sy1 * sstride + sx1] : 0;
+                v = v0 * w00 + v1 * w01 + v2 * w10 + v3 * w11;
+            }
+            v = (v + (1 << 14)) >> 15;  // FixedPtCast<int, uchar, 15>
+            D[x] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+}

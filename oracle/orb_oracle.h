@@ -25,6 +25,9 @@
  *       an empty match list leaves every output at -1 (the reference indexes an empty
  *       vector at :646); right keypoints whose row band leaves [0, rows) only fill the rows
  *       that exist (the reference writes out of bounds at :511).
+ *   D8  input staging restates OpenCV 3.4.5's 8-bit paths: gray = 14-bit fixed point with
+ *       coefficients 1868/9617/4899; remap = maps rounded to 1/32 px (round half to even),
+ *       15-bit bilinear weights.  Later OpenCV releases changed the gray coefficients.
  *   D6  a = cos, b = sin of the float32 radian angle are float32 roundings of a
  *       double-precision evaluation (fixed range reduction + fdlibm kernels, explicit
  *       fma) -- the correctly rounded value on every input checked.
@@ -121,6 +124,22 @@ int orc_descriptor_distance(const uint8_t a[32], const uint8_t b[32]);
    each accepted match before the median cut, -1 elsewhere.  Returns the matches kept. */
 int orc_stereo_match(const orc_ctx* left, const orc_ctx* right, float mb, float mbf,
                      float* u_right, float* depth, int32_t* sad);
+
+
+/* ---- the stage before the extractor: input staging ---------------------------------------- */
+/* cv::cvtColor(src, dst, CV_{BGR,RGB,BGRA,RGBA}2GRAY) on 8-bit images, the call of
+   Tracking::GrabImage* (reference src/Tracking.cc:175-199, 213-231, 250-268).  OpenCV 3.4.5
+   fixed-point form: (B*1868 + G*9617 + R*4899 + 8192) >> 14.  channels = 3 or 4 (alpha ignored),
+   blue_idx = 0 for BGR(A) order, 2 for RGB(A). */
+void orc_cvt_gray(const uint8_t* src, int w, int h, int sstride, int channels, int blue_idx,
+                  uint8_t* dst, int dstride);
+/* cv::remap(src, dst, mapx, mapy, INTER_LINEAR) with CV_32FC1 maps, 8UC1 image, BORDER_CONSTANT 0:
+   the rectification of the stereo examples (reference Examples/Stereo/stereo_euroc.cc:137-138).
+   OpenCV 3.4.5 fixed-point form: map coordinates rounded to 1/32 px, bilinear weights
+   (32-fx)(32-fy)*32 ... summing to 32768, result (sum + 16384) >> 15.  Maps are dw x dh floats,
+   rows map_stride floats apart. */
+void orc_remap_linear(const uint8_t* src, int sw, int sh, int sstride, const float* mapx,
+                      const float* mapy, int map_stride, uint8_t* dst, int dw, int dh, int dstride);
 
 #ifdef __cplusplus
 }

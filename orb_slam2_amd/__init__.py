@@ -47,7 +47,7 @@ EXPORTS = [
     "orbx_create", "orbx_destroy", "orbx_extract", "orbx_extract_batch", "orbx_extract_batch_device",
     "orbx_synchronize", "orbx_pyramid_level", "orbx_debug_read", "orbx_set_profiling", "orbx_get_stage_ms",
     "orbx_stage_name", "orbx_strerror", "orbx_last_hip_error", "orbx_version",
-    "orbx_stereo_match", "orbx_stereo_match_batch_device",
+    "orbx_stereo_match", "orbx_stereo_match_batch_device", "orbx_gray_batch_device", "orbx_remap_batch_device",
 ]
 
 _lib = None
@@ -76,6 +76,9 @@ def load_library():
     L.orbx_synchronize.argtypes = [vp]
     L.orbx_stereo_match.argtypes = [vp, i32, vp, i32, f32, f32, vp, vp, i32, C.POINTER(i32)]
     L.orbx_stereo_match_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, f32, f32, vp, vp, i32]
+    L.orbx_gray_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, i32, i32, vp, i32, C.c_size_t, i32]
+    L.orbx_remap_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, vp, vp, i32, vp, i32, i32, i32,
+                                          C.c_size_t, i32]
     L.orbx_pyramid_level.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.orbx_debug_read.argtypes = [vp, i32, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.orbx_set_profiling.argtypes = [vp, i32]
@@ -255,6 +258,23 @@ class ORBextractor:
 
     def synchronize(self):
         _check(self._L.orbx_synchronize(self._ctx), self._ctx)
+
+    # ---- the stage before the extractor: gray conversion and rectification, device memory ----
+    def gray_batch_device(self, n, d_src, width, height, src_stride, src_frame_stride, channels, blue_idx, d_dst,
+                          dst_stride, dst_frame_stride, sync=True):
+        """cv::cvtColor(..., CV_*2GRAY) of Tracking::GrabImage* (src/Tracking.cc:175-199); raw device addresses."""
+        _check(self._L.orbx_gray_batch_device(self._ctx, n, C.c_void_p(d_src), width, height, src_stride, src_frame_stride,
+                                              channels, blue_idx, C.c_void_p(d_dst), dst_stride, dst_frame_stride,
+                                              int(sync)), self._ctx)
+
+    def remap_batch_device(self, n, d_src, src_width, src_height, src_stride, src_frame_stride, d_mapx, d_mapy, map_stride,
+                           d_dst, dst_width, dst_height, dst_stride, dst_frame_stride, sync=True):
+        """cv::remap(..., INTER_LINEAR) of the stereo examples (Examples/Stereo/stereo_euroc.cc:137); raw device
+        addresses."""
+        _check(self._L.orbx_remap_batch_device(self._ctx, n, C.c_void_p(d_src), src_width, src_height, src_stride,
+                                               src_frame_stride, C.c_void_p(d_mapx), C.c_void_p(d_mapy), map_stride,
+                                               C.c_void_p(d_dst), dst_width, dst_height, dst_stride, dst_frame_stride,
+                                               int(sync)), self._ctx)
 
     # ---- the stage after the extractor: Frame::ComputeStereoMatches (src/Frame.cc:485-659) ----
     def stereo_match(self, right, mb, mbf, img_left=0, img_right=0):

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void k_blur7_all(BatchDev B) {
     for (int r = 0; r < kBlurRows + 6; ++r) {
         const uint32_t Lw = qL[r % kBlurPF], C = qC[r % kBlurPF], R = qR[r % kBlurPF];
         if (r + kBlurPF < kBlurRows + 6) {
-            const int vo = ((B.dbg & 2) ? 0 : reflect101(min(y0 + r + kBlurPF - 3, h + 2), h) * spitch) + vcol;
+            const int vo = reflect101(min(y0 + r + kBlurPF - 3, h + 2), h) * spitch + vcol;
             qL[r % kBlurPF] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0, 0);
             qC[r % kBlurPF] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo + 4, 0, 0);
             qR[r % kBlurPF] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo + 8, 0, 0);
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void k_blur7_all(BatchDev B) {
             const int y = y0 + r - 6;
             const uint32_t o = blur_col(pr, wr[0], r, 0) | (blur_col(pr, wr[1], r, 1) << 8) |
                                (blur_col(pr, wr[2], r, 2) << 16) | (blur_col(pr, wr[3], r, 3) << 24);
-            const int vs = (store_ok && y < h && !(B.dbg & 1)) ? y * dpitch + x0 : kOut;
+            const int vs = (store_ok && y < h) ? y * dpitch + x0 : kOut;
             __builtin_amdgcn_raw_buffer_store_b32(o, rd, vs, 0, 0);
         }
 #pragma unroll

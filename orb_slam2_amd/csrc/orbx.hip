@@ -15,6 +15,7 @@
 #include "kernels_fast.hpp"
 #include "kernels_octree.hpp"
 #include "kernels_pyramid.hpp"
+#include "kernels_staging.hpp"
 #include "kernels_stereo.hpp"
 #include "orbx_device.h"
 #include "orbx_host.h"
@@ -295,10 +296,6 @@ void fill_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_p
     if (!c->d_stamps.p && ensure(c, &c->d_stamps, 1024 * 16 * 8) == ORBX_OK) (void)hipMemset(c->d_stamps.p, 0, 1024 * 16 * 8);
     B.stamps = (unsigned long long*)c->d_stamps.p;
 #endif
-    {
-        const char* e = getenv("ORBX_DBG");
-        B.dbg = e ? atoi(e) : 0;
-    }
     size_t poff = 0, boff = 0;
     int dense_off = 0, kp_off = 0;
     const bool l0_in_arena = (l0 == nullptr);
@@ -797,6 +794,42 @@ extern "C" int orbx_stereo_match(orbx_ctx* left, int img_left, orbx_ctx* right, 
         HIP_TRY(left, hipMemcpy(u_right, left->d_st_u.p, (size_t)nl * 4, hipMemcpyDeviceToHost));
         HIP_TRY(left, hipMemcpy(depth, left->d_st_depth.p, (size_t)nl * 4, hipMemcpyDeviceToHost));
     }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_gray_batch_device(orbx_ctx* c, int n, const uint8_t* d_src, int width, int height, int src_stride,
+                                      size_t src_frame_stride, int channels, int blue_idx, uint8_t* d_dst,
+                                      int dst_stride, size_t dst_frame_stride, int sync) {
+    if (!c || !d_src || !d_dst || n < 1 || n > 65535 || width < 1 || height < 1 || height > 65535) return ORBX_E_INVALID;
+    if ((channels != 3 && channels != 4) || (blue_idx != 0 && blue_idx != 2)) return ORBX_E_INVALID;
+    if (src_stride < width * channels || dst_stride < width) return ORBX_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    const dim3 grid(((width + 3) / 4 + 255) / 256, height, n);
+    if (channels == 3)
+        hipLaunchKernelGGL(k_cvt_gray<3>, grid, dim3(256), 0, c->stream, d_src, src_stride, (uint64_t)src_frame_stride,
+                           d_dst, dst_stride, (uint64_t)dst_frame_stride, width, blue_idx);
+    else
+        hipLaunchKernelGGL(k_cvt_gray<4>, grid, dim3(256), 0, c->stream, d_src, src_stride, (uint64_t)src_frame_stride,
+                           d_dst, dst_stride, (uint64_t)dst_frame_stride, width, blue_idx);
+    HIP_TRY(c, hipGetLastError());
+    if (sync) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_remap_batch_device(orbx_ctx* c, int n, const uint8_t* d_src, int src_width, int src_height,
+                                       int src_stride, size_t src_frame_stride, const float* d_mapx, const float* d_mapy,
+                                       int map_stride, uint8_t* d_dst, int dst_width, int dst_height, int dst_stride,
+                                       size_t dst_frame_stride, int sync) {
+    if (!c || !d_src || !d_mapx || !d_mapy || !d_dst || n < 1 || n > 65535) return ORBX_E_INVALID;
+    if (src_width < 1 || src_height < 1 || dst_width < 1 || dst_height < 1 || dst_height > 65535) return ORBX_E_INVALID;
+    if (src_stride < src_width || dst_stride < dst_width || map_stride < dst_width) return ORBX_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    const dim3 grid(((dst_width + 3) / 4 + 255) / 256, dst_height, n);
+    hipLaunchKernelGGL(k_remap_linear, grid, dim3(256), 0, c->stream, d_src, src_width, src_height, src_stride,
+                       (uint64_t)src_frame_stride, d_mapx, d_mapy, map_stride, d_dst, dst_width, dst_stride,
+                       (uint64_t)dst_frame_stride);
+    HIP_TRY(c, hipGetLastError());
+    if (sync) HIP_TRY(c, hipStreamSynchronize(c->stream));
     return ORBX_OK;
 }
 

@@ -22,8 +22,10 @@ __host__ __device__ inline int pt_x(uint32_t p) { return (int)(p & 0xFFFu); }
 __host__ __device__ inline int pt_y(uint32_t p) { return (int)((p >> 12) & 0xFFFu); }
 __host__ __device__ inline int pt_score(uint32_t p) { return (int)(p >> 24); }
 
-// Loads at byte-granular addresses: gfx950 global and LDS loads of 4 and 16 bytes need no alignment.
+// Loads at byte-granular addresses: gfx950 global loads of 2, 4 and 16 bytes and
+// LDS loads of 4 bytes need no alignment.
 typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+typedef uint16_t u16_unaligned __attribute__((aligned(1)));
 struct __attribute__((packed, aligned(1))) uint4_unaligned {
     uint32_t x, y, z, w;
     __device__ operator uint4() const { return make_uint4(x, y, z, w); }
@@ -62,7 +64,7 @@ struct BatchDev {
     int32_t kp_total;      // retained points per frame over all levels (sum of max_kp)
     int32_t ini_th, min_th;
     unsigned long long* stamps;  // cycle sums per phase, diagnostic builds only (null otherwise)
-    int32_t dbg;           // ablation switches for timing experiments (0 in normal operation)
+    int32_t pad0;
     int32_t blur_first[ORBX_MAX_LEVELS + 1];  // first blur block of each level; [nlevels] = total
 };
 

@@ -84,6 +84,9 @@ def lib():
         L.orc_get_num_level_keypoints.argtypes = [C.c_void_p, C.c_int]
         L.orc_get_level_padded.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_remap_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         _ = u8p
         _lib = L
@@ -173,6 +176,26 @@ def descriptor(blurred, x, y, angle):
 def pattern():
     p = lib().orc_pattern()
     return np.ctypeslib.as_array(p, shape=(1024,)).copy()
+
+
+def cvt_gray(src, blue_idx):
+    """src: h x w x (3|4) uint8; blue_idx 0 = BGR(A), 2 = RGB(A)."""
+    src = np.ascontiguousarray(src, np.uint8)
+    h, w, ch = src.shape
+    dst = np.zeros((h, w), np.uint8)
+    lib().orc_cvt_gray(_ptr(src), w, h, src.strides[0], ch, blue_idx, _ptr(dst), w)
+    return dst
+
+
+def remap_linear(src, mapx, mapy):
+    src = np.ascontiguousarray(src, np.uint8)
+    mapx = np.ascontiguousarray(mapx, np.float32)
+    mapy = np.ascontiguousarray(mapy, np.float32)
+    dh, dw = mapx.shape
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_remap_linear(_ptr(src), src.shape[1], src.shape[0], src.strides[0], _ptr(mapx), _ptr(mapy), dw, _ptr(dst),
+                           dw, dh, dw)
+    return dst
 
 
 def descriptor_distance(a, b):
