@@ -149,6 +149,24 @@ int orbx_remap_batch_device(orbx_ctx* ctx, int n, const uint8_t* d_src, int src_
                             const float* d_mapy, int map_stride, uint8_t* d_dst, int dst_width,
                             int dst_height, int dst_stride, size_t dst_frame_stride, int sync);
 
+/* ---- right after the extractor: undistorted keypoints and the frame grid ------------------
+ * Replaces Frame::UndistortKeyPoints (reference src/Frame.cc:421-451: cv::undistortPoints with
+ * R = I, P = K, OpenCV 3.4.5's five double-precision iterations; dist[0] == 0 copies) and
+ * Frame::AssignFeaturesToGrid / PosInGrid (reference src/Frame.cc:232-247, 398-408) for every
+ * frame of a batch in device memory.  K = {fx, fy, cx, cy}, dist = {k1, k2, p1, p2, k3} (host
+ * pointers); min_x, min_y, inv_w, inv_h are Frame's mnMinX, mnMinY, mfGridElementWidthInv,
+ * mfGridElementHeightInv (src/Frame.cc:101-102, 452-482).  d_kps_un[n*kp_cap] receives the
+ * keypoints with undistorted coordinates (mvKeysUn); the 64 x 48 grid comes back in CSR form:
+ * cell gx*48 + gy of frame f holds d_cell_idx[f*kp_cap + s .. e) with s, e =
+ * d_cell_start[f*3073 + cell], [.. + cell + 1], indices ascending (mGrid's push_back order). */
+#define ORBX_GRID_COLS 64
+#define ORBX_GRID_ROWS 48
+int orbx_undistort_grid_batch_device(orbx_ctx* ctx, int n, const orbx_kp* d_kps, int kp_cap,
+                                     const int32_t* d_n, const float K[4], const float dist[5],
+                                     float min_x, float min_y, float inv_w, float inv_h,
+                                     orbx_kp* d_kps_un, int32_t* d_cell_start, int32_t* d_cell_idx,
+                                     int sync);
+
 /* ---- the stage after the extractor: stereo association ---------------------------------
  * Replaces Frame::ComputeStereoMatches (reference src/Frame.cc:485-659, descriptor distance
  * src/ORBmatcher.cc:1684-1700): for every left keypoint the best right keypoint in its row

@@ -1009,3 +1009,58 @@ extern "C" void orc_remap_linear(const uint8_t* src, int sw, int sh, int sstride
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Undistorted keypoints and the frame grid (reference src/Frame.cc:421-451, 232-247, 398-408).
+// ---------------------------------------------------------------------------------------------
+
+// cvUndistortPointsInternal of OpenCV 3.4.5 with R = I, P = K, distortion (k1,k2,p1,p2,k3), no
+// tilt, criteria (MAX_ITER, 5): all arithmetic in double, statements in OpenCV's order.
+extern "C" void orc_undistort_points(const float* xy_in, int n, const float K[4], const float dist[5], float* xy_out) {
+    if (dist[0] == 0.0f) {  // src/Frame.cc:423-427
+        std::memcpy(xy_out, xy_in, (size_t)n * 2 * sizeof(float));
+        return;
+    }
+    const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+    const double ifx = 1. / fx, ify = 1. / fy;
+    const double k[5] = {dist[0], dist[1], dist[2], dist[3], dist[4]};
+    for (int i = 0; i < n; i++) {
+        double x = xy_in[2 * i], y = xy_in[2 * i + 1];
+        x = (x - cx) * ifx;
+        y = (y - cy) * ify;
+        const double x0 = x, y0 = y;
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            // k[5..7] (rational model) and k[8..11] (thin prism) are zero
+            const double icdist = (1 + ((0. * r2 + 0.) * r2 + 0.) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + 0. * r2 + 0. * r2 * r2;
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + 0. * r2 + 0. * r2 * r2;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        // RR = K * I: xx = fx*x + 0*y + cx, yy = 0*x + fy*y + cy, ww = 1/(0*x + 0*y + 1)
+        const double xx = fx * x + 0. * y + cx;
+        const double yy = 0. * x + fy * y + cy;
+        const double ww = 1. / (0. * x + 0. * y + 1.);
+        xy_out[2 * i] = (float)(xx * ww);
+        xy_out[2 * i + 1] = (float)(yy * ww);
+    }
+}
+
+extern "C" void orc_assign_grid(const float* xy, int n, float min_x, float min_y, float inv_w, float inv_h,
+                                int32_t* cell_start, int32_t* idx) {
+    const int COLS = 64, ROWS = 48;  // include/Frame.h:37-38
+    std::vector<std::vector<int> > grid((size_t)COLS * ROWS);
+    for (int i = 0; i < n; i++) {
+        const int posX = (int)roundf((xy[2 * i] - min_x) * inv_w);  // :400-401
+        const int posY = (int)roundf((xy[2 * i + 1] - min_y) * inv_h);
+        if (posX < 0 || posX >= COLS || posY < 0 || posY >= ROWS) continue;
+        grid[(size_t)posX * ROWS + posY].push_back(i);
+    }
+    int at = 0;
+    for (int c = 0; c < COLS * ROWS; c++) {
+        cell_start[c] = at;
+        for (size_t k = 0; k < grid[c].size(); k++) idx[at++] = grid[c][k];
+    }
+    cell_start[COLS * ROWS] = at;
+}

@@ -28,6 +28,7 @@
  *   D8  input staging restates OpenCV 3.4.5's 8-bit paths: gray = 14-bit fixed point with
  *       coefficients 1868/9617/4899; remap = maps rounded to 1/32 px (round half to even),
  *       15-bit bilinear weights.  Later OpenCV releases changed the gray coefficients.
+ *   D9  cv::undistortPoints as in OpenCV 3.4.5: exactly 5 iterations, IEEE double, no contraction.
  *   D6  a = cos, b = sin of the float32 radian angle are float32 roundings of a
  *       double-precision evaluation (fixed range reduction + fdlibm kernels, explicit
  *       fma) -- the correctly rounded value on every input checked.
@@ -140,6 +141,20 @@ void orc_cvt_gray(const uint8_t* src, int w, int h, int sstride, int channels, i
    rows map_stride floats apart. */
 void orc_remap_linear(const uint8_t* src, int sw, int sh, int sstride, const float* mapx,
                       const float* mapy, int map_stride, uint8_t* dst, int dw, int dh, int dstride);
+
+
+/* ---- right after the extractor: undistorted keypoints and the frame grid -------------------- */
+/* Frame::UndistortKeyPoints (reference src/Frame.cc:421-451): cv::undistortPoints(pts, pts, K, D,
+   Mat(), K) of OpenCV 3.4.5 -- normalise, 5 fixed-point iterations of the inverse distortion
+   model in double precision, re-project with K, round to float.  K = {fx, fy, cx, cy},
+   dist = {k1, k2, p1, p2, k3}.  dist[0] == 0 copies the input (:423-427).  xy: n (x, y) pairs. */
+void orc_undistort_points(const float* xy_in, int n, const float K[4], const float dist[5], float* xy_out);
+/* Frame::AssignFeaturesToGrid + PosInGrid (reference src/Frame.cc:232-247, 398-408): cell
+   (round((x-min_x)*inv_w), round((y-min_y)*inv_h)) of a 64 x 48 grid; points outside are
+   dropped.  CSR output: cell c = gx*48 + gy holds idx[cell_start[c] .. cell_start[c+1]) in
+   ascending keypoint order (the push_back order).  cell_start has 64*48+1 entries. */
+void orc_assign_grid(const float* xy, int n, float min_x, float min_y, float inv_w, float inv_h,
+                     int32_t* cell_start, int32_t* idx);
 
 #ifdef __cplusplus
 }

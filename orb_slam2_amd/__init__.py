@@ -48,6 +48,7 @@ EXPORTS = [
     "orbx_synchronize", "orbx_pyramid_level", "orbx_debug_read", "orbx_set_profiling", "orbx_get_stage_ms",
     "orbx_stage_name", "orbx_strerror", "orbx_last_hip_error", "orbx_version",
     "orbx_stereo_match", "orbx_stereo_match_batch_device", "orbx_gray_batch_device", "orbx_remap_batch_device",
+    "orbx_undistort_grid_batch_device",
 ]
 
 _lib = None
@@ -76,6 +77,7 @@ def load_library():
     L.orbx_synchronize.argtypes = [vp]
     L.orbx_stereo_match.argtypes = [vp, i32, vp, i32, f32, f32, vp, vp, i32, C.POINTER(i32)]
     L.orbx_stereo_match_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, f32, f32, vp, vp, i32]
+    L.orbx_undistort_grid_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, f32, f32, f32, f32, vp, vp, vp, i32]
     L.orbx_gray_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, i32, i32, vp, i32, C.c_size_t, i32]
     L.orbx_remap_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, vp, vp, i32, vp, i32, i32, i32,
                                           C.c_size_t, i32]
@@ -275,6 +277,19 @@ class ORBextractor:
                                                src_frame_stride, C.c_void_p(d_mapx), C.c_void_p(d_mapy), map_stride,
                                                C.c_void_p(d_dst), dst_width, dst_height, dst_stride, dst_frame_stride,
                                                int(sync)), self._ctx)
+
+    # ---- right after the extractor: Frame::UndistortKeyPoints + AssignFeaturesToGrid ----
+    def undistort_grid_batch_device(self, n, d_kps, kp_cap, d_n, K, dist, min_x, min_y, inv_w, inv_h, d_kps_un,
+                                    d_cell_start, d_cell_idx, sync=True):
+        """mvKeysUn and mGrid (src/Frame.cc:421-451, 232-247) for every frame of a batch; K = (fx, fy, cx, cy),
+        dist = (k1, k2, p1, p2, k3); raw device addresses; see orbx_undistort_grid_batch_device."""
+        K = np.ascontiguousarray(K, np.float32)
+        dist = np.ascontiguousarray(dist, np.float32)
+        assert K.size == 4 and dist.size == 5
+        _check(self._L.orbx_undistort_grid_batch_device(self._ctx, n, C.c_void_p(d_kps), kp_cap, C.c_void_p(d_n), _ptr(K),
+                                                        _ptr(dist), min_x, min_y, inv_w, inv_h, C.c_void_p(d_kps_un),
+                                                        C.c_void_p(d_cell_start), C.c_void_p(d_cell_idx), int(sync)),
+               self._ctx)
 
     # ---- the stage after the extractor: Frame::ComputeStereoMatches (src/Frame.cc:485-659) ----
     def stereo_match(self, right, mb, mbf, img_left=0, img_right=0):

@@ -14,6 +14,7 @@
 #include "kernels_describe.hpp"
 #include "kernels_fast.hpp"
 #include "kernels_octree.hpp"
+#include "kernels_post.hpp"
 #include "kernels_pyramid.hpp"
 #include "kernels_staging.hpp"
 #include "kernels_stereo.hpp"
@@ -828,6 +829,21 @@ extern "C" int orbx_remap_batch_device(orbx_ctx* c, int n, const uint8_t* d_src,
     hipLaunchKernelGGL(k_remap_linear, grid, dim3(256), 0, c->stream, d_src, src_width, src_height, src_stride,
                        (uint64_t)src_frame_stride, d_mapx, d_mapy, map_stride, d_dst, dst_width, dst_stride,
                        (uint64_t)dst_frame_stride);
+    HIP_TRY(c, hipGetLastError());
+    if (sync) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_undistort_grid_batch_device(orbx_ctx* c, int n, const orbx_kp* d_kps, int kp_cap, const int32_t* d_n,
+                                                const float K[4], const float dist[5], float min_x, float min_y,
+                                                float inv_w, float inv_h, orbx_kp* d_kps_un, int32_t* d_cell_start,
+                                                int32_t* d_cell_idx, int sync) {
+    if (!c || !d_kps || !d_n || !K || !dist || !d_kps_un || !d_cell_start || !d_cell_idx || n < 1 || kp_cap < 1)
+        return ORBX_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    PostParams P = {K[0], K[1], K[2], K[3], dist[0], dist[1], dist[2], dist[3], dist[4], min_x, min_y, inv_w, inv_h};
+    hipLaunchKernelGGL(k_undistort_grid, dim3(n), dim3(256), 0, c->stream, P, d_kps, d_n, kp_cap, d_kps_un, d_cell_start,
+                       d_cell_idx);
     HIP_TRY(c, hipGetLastError());
     if (sync) HIP_TRY(c, hipStreamSynchronize(c->stream));
     return ORBX_OK;

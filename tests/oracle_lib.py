@@ -84,6 +84,8 @@ def lib():
         L.orc_get_num_level_keypoints.argtypes = [C.c_void_p, C.c_int]
         L.orc_get_level_padded.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_undistort_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_assign_grid.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.orc_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.orc_remap_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -196,6 +198,24 @@ def remap_linear(src, mapx, mapy):
     lib().orc_remap_linear(_ptr(src), src.shape[1], src.shape[0], src.strides[0], _ptr(mapx), _ptr(mapy), dw, _ptr(dst),
                            dw, dh, dw)
     return dst
+
+
+def undistort_points(xy, K, dist):
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    K = np.ascontiguousarray(K, np.float32)
+    dist = np.ascontiguousarray(dist, np.float32)
+    assert K.size == 4 and dist.size == 5
+    out = np.zeros_like(xy)
+    lib().orc_undistort_points(_ptr(xy), len(xy), _ptr(K), _ptr(dist), _ptr(out))
+    return out
+
+
+def assign_grid(xy, min_x, min_y, inv_w, inv_h):
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    start = np.zeros(64 * 48 + 1, np.int32)
+    idx = np.zeros(max(1, len(xy)), np.int32)
+    lib().orc_assign_grid(_ptr(xy), len(xy), min_x, min_y, inv_w, inv_h, _ptr(start), _ptr(idx))
+    return start, idx[:start[-1]]
 
 
 def descriptor_distance(a, b):
