@@ -133,16 +133,26 @@ def main():
     import torch
     import torch.distributed as dist
     import orb_slam2_amd as oa
+    from orb_slam2_amd import shard
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # ORBX_BENCH_BACKEND=gloo rehearses the multi-process flow on a box with fewer GPUs than ranks
+    # (ranks then share devices); the measured configuration is one rank per GPU over RCCL ("nccl").
+    backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
+    red_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=red_dev)
+        else:
+            dist.init_process_group(backend)
 
     n = 2 * args.pairs
     stride = (W + 63) // 64 * 64
@@ -179,11 +189,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = shard.max_over_ranks(time.perf_counter() - t0, dist, red_dev)  # the job is as slow as its slowest rank
 
     # the stage after the extractor (stereo association of the pairs of the batch), timed on its own:
     # it is not part of `value`
