@@ -38,6 +38,10 @@ struct DevBuf {
 
 }  // namespace
 
+enum {  // timing events of one batch
+    kEvPyr0, kEvPyr1, kEvFastA0, kEvFastA1, kEvFastB0, kEvFastB1, kEvOct1, kEvBlur0, kEvBlur1, kEvDesc0, kEvDesc1, kEvCount
+};
+
 struct orbx_ctx {
     orbx_params prm;
     Tables tab;
@@ -84,11 +88,16 @@ struct orbx_ctx {
     hipStream_t st_up = nullptr, st_down = nullptr;
     hipEvent_t ev_up[2], ev_done[2], ev_down[2];
     bool pipe_made = false;
+    // auxiliary compute stream (pyramid + blur beside FAST + quadtree) and its ordering events
+    hipStream_t st_aux = nullptr;
+    hipEvent_t ev_start, ev_pyr_done, ev_blur_done;
+    bool aux_made = false;
+    int tiles_level0 = 0;  // the first tiles_level0 entries of `tiles` belong to level 0
     // stereo stage scratch (grown on demand)
     DevBuf d_st_rows, d_st_meta, d_st_wmax, d_st_sad, d_st_u, d_st_depth;
 
     bool profiling = false;
-    hipEvent_t ev[ORBX_NUM_STAGES + 1];
+    hipEvent_t ev[kEvCount];  // timing events, recorded when profiling is on
     bool ev_made = false;
     bool ev_valid = false;
 };
@@ -209,6 +218,8 @@ int set_geometry(orbx_ctx* c, int w, int h) {
     c->levels.swap(levels);
     c->cells.swap(cells);
     c->tiles.swap(tiles);
+    c->tiles_level0 = 0;
+    for (const TileDesc& t : c->tiles) c->tiles_level0 += t.level == 0 ? 1 : 0;
     c->fast_tile_bytes = tile_b;
     c->fast_plane_bytes = plane_b;
     c->fast_queue_bytes = queue_b;
@@ -344,34 +355,83 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     fill_batch(c, n, l0, l0_pitch, l0_plane, n_total < 0 ? n : n_total, frame0);
     const int L = c->tab.nlevels;
     BatchDev& B = c->B;
+    // Two streams.  The auxiliary (low-priority) stream builds the pyramid and then blurs it; the
+    // main stream runs FAST on level 0 (which needs no pyramid) at once, FAST on the other levels
+    // when the pyramid is there, the quadtree, and the descriptors once the blur has finished.
+    // The memory-bound pyramid and blur so fill what the VALU-bound FAST and the latency-bound
+    // quadtree leave idle.  ORBX_NO_OVERLAP=1 puts everything on the main stream in stage order.
+    const bool overlap = std::getenv("ORBX_NO_OVERLAP") == nullptr;
     hipStream_t st = c->stream;
+    if (overlap && !c->aux_made) {
+        int prio_lo = 0, prio_hi = 0;
+        HIP_TRY(c, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        HIP_TRY(c, hipStreamCreateWithPriority(&c->st_aux, hipStreamNonBlocking, prio_lo));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pyr_done, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_blur_done, hipEventDisableTiming));
+        c->aux_made = true;
+    }
+    hipStream_t aux = overlap ? c->st_aux : st;
     const bool prof = c->profiling;
-    if (prof) HIP_TRY(c, hipEventRecord(c->ev[0], st));
-    // stage 0: pyramid
+    auto mark = [&](int i, hipStream_t s) -> int {  // timing event i (see orbx_get_stage_ms)
+        if (prof) HIP_TRY(c, hipEventRecord(c->ev[i], s));
+        return ORBX_OK;
+    };
+    int rc;
+    const int n_tiles = (int)c->tiles.size(), n_tiles0 = c->tiles_level0;
+    auto launch_fast = [&](int first, int count) {
+        if (count > 0)
+            hipLaunchKernelGGL(k_fast_tiles, dim3((unsigned)count, n), dim3(256), c->fast_lds, st, B,
+                               (const TileDesc*)c->d_tiles.p + first, (uint32_t*)c->d_cand.p, (uint32_t*)c->d_ccount.p,
+                               c->fast_tile_bytes, c->fast_plane_bytes, c->fast_queue_bytes);
+    };
+    if (overlap) {
+        // level 0 and the arenas are ready when the main stream gets here
+        HIP_TRY(c, hipEventRecord(c->ev_start, st));
+        HIP_TRY(c, hipStreamWaitEvent(aux, c->ev_start, 0));
+    }
+    // stage 0 (aux): pyramid
+    if ((rc = mark(kEvPyr0, aux))) return rc;
     for (int l = 1; l < L; ++l) {
         const LevelDev& S = B.lv[l - 1];
         const LevelDev& D = B.lv[l];
         dim3 grid((D.w + kRsTW - 1) / kRsTW, (D.h + kRsTH - 1) / kRsTH, n);
         const size_t lds = (size_t)c->rs_pitch[l] * c->rs_rows[l] + (kRsTW + kRsTH) * sizeof(ResizeTap);
-        hipLaunchKernelGGL(k_resize, grid, dim3(256), lds, st, S.img, S.pitch, S.plane, S.w, S.h,
+        hipLaunchKernelGGL(k_resize, grid, dim3(256), lds, aux, S.img, S.pitch, S.plane, S.w, S.h,
                            const_cast<uint8_t*>(D.img), D.pitch, D.plane, D.w, D.h, (const ResizeTap*)c->d_xt[l].p,
                            (const ResizeTap*)c->d_yt[l].p, c->rs_pitch[l], c->rs_rows[l]);
     }
-    if (prof) HIP_TRY(c, hipEventRecord(c->ev[1], st));
-    // stage 1: FAST cells
-    hipLaunchKernelGGL(k_fast_tiles, dim3((unsigned)c->tiles.size(), n), dim3(256), c->fast_lds, st, B,
-                       (const TileDesc*)c->d_tiles.p, (uint32_t*)c->d_cand.p, (uint32_t*)c->d_ccount.p,
-                       c->fast_tile_bytes, c->fast_plane_bytes, c->fast_queue_bytes);
-    if (prof) HIP_TRY(c, hipEventRecord(c->ev[2], st));
-    // stage 2: quadtree retention
+    if ((rc = mark(kEvPyr1, aux))) return rc;
+    if (overlap) {
+        HIP_TRY(c, hipEventRecord(c->ev_pyr_done, aux));
+        // stage 3 (aux): blur of all levels, behind the pyramid on the same stream
+        if ((rc = mark(kEvBlur0, aux))) return rc;
+        hipLaunchKernelGGL(k_blur7_all, dim3(B.blur_first[L], n), dim3(256), 0, aux, B);
+        if ((rc = mark(kEvBlur1, aux))) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev_blur_done, aux));
+    }
+    // stage 1 (main): FAST cells, level 0 first
+    if ((rc = mark(kEvFastA0, st))) return rc;
+    launch_fast(0, overlap ? n_tiles0 : 0);
+    if ((rc = mark(kEvFastA1, st))) return rc;
+    if (overlap) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_pyr_done, 0));
+    if ((rc = mark(kEvFastB0, st))) return rc;
+    launch_fast(overlap ? n_tiles0 : 0, overlap ? n_tiles - n_tiles0 : n_tiles);
+    if ((rc = mark(kEvFastB1, st))) return rc;
+    // stage 2 (main): quadtree retention
     hipLaunchKernelGGL(k_octree, dim3(L, n), dim3(256), c->oct_lds, st, B, (const uint32_t*)c->d_cand.p,
                        (const uint32_t*)c->d_ccount.p, (uint32_t*)c->d_dense_pts.p, (uint16_t*)c->d_dense_node.p,
                        (uint32_t*)c->d_lvl_kps.p, (int32_t*)c->d_lvl_count.p);
-    if (prof) HIP_TRY(c, hipEventRecord(c->ev[3], st));
-    // stage 3: blur, all levels in one launch
-    hipLaunchKernelGGL(k_blur7_all, dim3(B.blur_first[L], n), dim3(256), 0, st, B);
-    if (prof) HIP_TRY(c, hipEventRecord(c->ev[4], st));
-    // stage 4: orientation + descriptors + output assembly
+    if ((rc = mark(kEvOct1, st))) return rc;
+    if (overlap) {
+        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_blur_done, 0));
+    } else {
+        if ((rc = mark(kEvBlur0, st))) return rc;
+        hipLaunchKernelGGL(k_blur7_all, dim3(B.blur_first[L], n), dim3(256), 0, st, B);
+        if ((rc = mark(kEvBlur1, st))) return rc;
+    }
+    // stage 4 (main): orientation + descriptors + output assembly
+    if ((rc = mark(kEvDesc0, st))) return rc;
     {
         const int kp_blocks = (c->max_kp_level + kDescKp - 1) / kDescKp;
         const unsigned grid = 8u * (unsigned)((n + 7) / 8) * (unsigned)L * (unsigned)kp_blocks;
@@ -379,10 +439,8 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
                            (const int32_t*)c->d_lvl_count.p, (const int8_t*)c->d_pat.p, d_kps, d_desc, d_n_out, kp_cap,
                            kp_blocks);
     }
-    if (prof) {
-        HIP_TRY(c, hipEventRecord(c->ev[5], st));
-        c->ev_valid = true;
-    }
+    if ((rc = mark(kEvDesc1, st))) return rc;
+    if (prof) c->ev_valid = true;
     HIP_TRY(c, hipGetLastError());
     c->have_last = true;
     c->last_kps = d_kps;
@@ -611,7 +669,7 @@ extern "C" int orbx_create(const orbx_params* params, orbx_ctx** out) {
     };
     if (hipSetDevice(params->device_id) != hipSuccess) return fail(ORBX_E_HIP);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(ORBX_E_HIP);
-    for (int i = 0; i <= ORBX_NUM_STAGES; ++i)
+    for (int i = 0; i < kEvCount; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(ORBX_E_HIP);
     c->ev_made = true;
     if ((rc = ensure(c, &c->d_pat, sizeof(kPattern)))) return fail(rc);
@@ -652,6 +710,12 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
         if (c->h_up[i]) (void)hipHostFree(c->h_up[i]);
         if (c->h_res[i]) (void)hipHostFree(c->h_res[i]);
     }
+    if (c->aux_made) {
+        (void)hipEventDestroy(c->ev_start);
+        (void)hipEventDestroy(c->ev_pyr_done);
+        (void)hipEventDestroy(c->ev_blur_done);
+        (void)hipStreamDestroy(c->st_aux);
+    }
     if (c->pipe_made) {
         for (int i = 0; i < 2; ++i) {
             (void)hipEventDestroy(c->ev_up[i]);
@@ -666,7 +730,7 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
         release(&c->d_yt[l]);
     }
     if (c->ev_made)
-        for (int i = 0; i <= ORBX_NUM_STAGES; ++i) (void)hipEventDestroy(c->ev[i]);
+        for (int i = 0; i < kEvCount; ++i) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -942,8 +1006,22 @@ extern "C" int orbx_set_profiling(orbx_ctx* c, int enable) {
 extern "C" int orbx_get_stage_ms(orbx_ctx* c, float ms[ORBX_NUM_STAGES]) {
     if (!c || !ms) return ORBX_E_INVALID;
     if (!c->ev_valid) return ORBX_E_STATE;
-    HIP_TRY(c, hipEventSynchronize(c->ev[ORBX_NUM_STAGES]));
-    for (int i = 0; i < ORBX_NUM_STAGES; ++i) HIP_TRY(c, hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+    // each stage's own launches, start to end on the stream they ran on; with the two-stream
+    // schedule stages overlap, so the values can add up to more than the batch's wall time
+    HIP_TRY(c, hipEventSynchronize(c->ev[kEvDesc1]));
+    auto span = [&](int a, int b, float* out) -> int {
+        HIP_TRY(c, hipEventElapsedTime(out, c->ev[a], c->ev[b]));
+        return ORBX_OK;
+    };
+    float fa = 0.f, fb = 0.f;
+    int rc;
+    if ((rc = span(kEvPyr0, kEvPyr1, &ms[0]))) return rc;
+    if ((rc = span(kEvFastA0, kEvFastA1, &fa))) return rc;
+    if ((rc = span(kEvFastB0, kEvFastB1, &fb))) return rc;
+    ms[1] = fa + fb;
+    if ((rc = span(kEvFastB1, kEvOct1, &ms[2]))) return rc;
+    if ((rc = span(kEvBlur0, kEvBlur1, &ms[3]))) return rc;
+    if ((rc = span(kEvDesc0, kEvDesc1, &ms[4]))) return rc;
     return ORBX_OK;
 }
 
