@@ -32,12 +32,13 @@ STAGE_KERNEL = {"pyramid": "k_resize", "fast": "k_fast_tiles", "quadtree": "k_oc
                 "orient_describe": "k_orient_describe"}
 
 
-def measured_traffic(stage, frames_per_step):
-    """PMC-measured HBM bytes per launch of the stage's kernel, scaled to this run's batch size."""
+def measured_traffic(stage, frames_per_step, launches):
+    """PMC-measured HBM bytes per launch of the stage's kernel (its bytes per 512-frame step over its launches
+    per step), scaled to this run's batch size."""
     try:
         with open(TRAFFIC_FILE) as f:
             t = json.load(f)
-        return t[STAGE_KERNEL[stage]]["traffic_bytes"] * frames_per_step / 512.0
+        return t[STAGE_KERNEL[stage]]["traffic_bytes"] / launches * frames_per_step / 512.0
     except (OSError, KeyError, ValueError):
         return None
 
@@ -271,7 +272,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(dom, n),
+                "traffic": measured_traffic(dom, n, launches[dom]),
                 "algorithmic_bytes_per_launch": dom_bytes,
                 "kernel_ms_per_launch": stage_ms[dom] / launches[dom],
                 "note": "timed region: FAST runs as 2 launches (level 0, then levels 1..7) while the pyramid and the blur "

@@ -32,11 +32,14 @@ def main():
     d, out = sys.argv[1], sys.argv[2]
     rd = per_launch(d + "/rd/pmc_counter_collection.csv")
     wr = per_launch(d + "/wr/pmc_counter_collection.csv")
-    res = {"_note": "bytes per launch, averaged over the launches of `bench.py --steps 2 --warmup 1` (512 frames per "
-                    "step); fetch = 2 * FETCH_SIZE KiB (gfx950 correction, calibrated), write = WRITE_SIZE KiB"}
+    # one k_octree launch per extraction step: its launch count is the number of steps sampled
+    steps = rd["orbx::k_octree"][1]
+    res = {"_note": "bytes per extraction step (512 frames) summed over a kernel's launches of that step, averaged over "
+                    "the %d steps of `bench.py --steps 2 --warmup 1`; fetch = 2 * FETCH_SIZE KiB (gfx950 correction, "
+                    "calibrated), write = WRITE_SIZE KiB" % steps}
     for k in sorted(rd):
-        fetch = 2.0 * rd[k][0] * 1024.0
-        write = wr.get(k, (0.0, 0))[0] * 1024.0
+        fetch = 2.0 * rd[k][0] * rd[k][1] * 1024.0 / steps
+        write = wr.get(k, (0.0, 0))[0] * wr.get(k, (0.0, 0))[1] * 1024.0 / steps
         res[k.replace("orbx::", "")] = {"launches_sampled": rd[k][1], "fetch_bytes": fetch, "write_bytes": write,
                                         "traffic_bytes": fetch + write}
     with open(out, "w") as f:
