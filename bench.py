@@ -183,10 +183,11 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-        ex.synchronize()
-        for k, v in ex.stage_ms().items():  # HIP events recorded on the extractor's stream
-            stage_sum[k] = stage_sum.get(k, 0.0) + v
+        step()          # steps are enqueued back to back: a batch's descriptors overlap the next batch's FAST
+    ex.synchronize()    # the extractor's own streams (torch's current stream never sees them)
+    # HIP events recorded on the extractor's streams around each stage's launches; the events of the last
+    # step of the timed region are the ones left to read
+    stage_sum = {k: v * args.steps for k, v in ex.stage_ms().items()}
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()

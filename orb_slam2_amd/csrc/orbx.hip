@@ -90,8 +90,9 @@ struct orbx_ctx {
     bool pipe_made = false;
     // auxiliary compute stream (pyramid + blur beside FAST + quadtree) and its ordering events
     hipStream_t st_aux = nullptr;
-    hipEvent_t ev_start, ev_pyr_done, ev_blur_done;
+    hipEvent_t ev_start, ev_pyr_done, ev_oct_done, ev_desc_done;
     bool aux_made = false;
+    bool desc_pending = false;  // the last batch's descriptors may still be running on the auxiliary stream
     int tiles_level0 = 0;  // the first tiles_level0 entries of `tiles` belong to level 0
     // stereo stage scratch (grown on demand)
     DevBuf d_st_rows, d_st_meta, d_st_wmax, d_st_sad, d_st_u, d_st_depth;
@@ -113,10 +114,26 @@ namespace {
         }                                         \
     } while (0)
 
+// The descriptors of a batch run on the auxiliary stream (see run_batch).  join() makes everything
+// enqueued on the main stream from here on wait for them; sync_ctx() also drains the main stream.
+int join(orbx_ctx* c) {
+    if (c->desc_pending) {
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_desc_done, 0));
+        c->desc_pending = false;
+    }
+    return ORBX_OK;
+}
+int sync_ctx(orbx_ctx* c) {
+    int rc = join(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ORBX_OK;
+}
+
 int ensure(orbx_ctx* c, DevBuf* b, size_t bytes) {
     if (bytes <= b->bytes) return ORBX_OK;
     if (b->p) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        { int rc_ = sync_ctx(c); if (rc_) return rc_; }
         HIP_TRY(c, hipFree(b->p));
         b->p = nullptr;
         b->bytes = 0;
@@ -170,7 +187,7 @@ int set_geometry(orbx_ctx* c, int w, int h) {
     plane_b = (int)align_up((size_t)plane_b, 16);
     const size_t fast_lds = (size_t)tile_b + (size_t)plane_b + (size_t)queue_b + (size_t)kept_b + 16;
     if (fast_lds > 160 * 1024 - 256) return ORBX_E_GEOMETRY;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     rc = ensure(c, &c->d_cells, cells.size() * sizeof(CellDesc));
     if (rc) return rc;
     HIP_TRY(c, hipMemcpy(c->d_cells.p, cells.data(), cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
@@ -241,7 +258,7 @@ constexpr size_t kStageMax = (size_t)64 << 20;  // staging chunk for uploads
 int ensure_stage(orbx_ctx* c, size_t bytes) {
     if (bytes <= c->h_stage_bytes) return ORBX_OK;
     if (c->h_stage) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        { int rc_ = sync_ctx(c); if (rc_) return rc_; }
         HIP_TRY(c, hipHostFree(c->h_stage));
         c->h_stage = nullptr;
         c->h_stage_bytes = 0;
@@ -258,9 +275,10 @@ int upload_level0(orbx_ctx* c, int n, const uint8_t* const* imgs, const int* str
     const int per_chunk = (int)std::max<size_t>(1, kStageMax / plane);
     int rc = ensure_stage(c, plane * (size_t)std::min(n, per_chunk));
     if (rc) return rc;
+    if ((rc = join(c))) return rc;  // level 0 of the arena is still read by the previous batch's descriptors
     for (int i0 = 0; i0 < n; i0 += per_chunk) {
         const int m = std::min(per_chunk, n - i0);
-        if (i0 > 0) HIP_TRY(c, hipStreamSynchronize(c->stream));  // the previous chunk has left the staging buffer
+        if (i0 > 0) { int rc_ = sync_ctx(c); if (rc_) return rc_; }  // the previous chunk has left the staging buffer
         for (int i = 0; i < m; ++i) {
             uint8_t* d = (uint8_t*)c->h_stage + (size_t)i * plane;
             const uint8_t* s = imgs[i0 + i];
@@ -368,7 +386,8 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
         HIP_TRY(c, hipStreamCreateWithPriority(&c->st_aux, hipStreamNonBlocking, prio_lo));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pyr_done, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_blur_done, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_oct_done, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_desc_done, hipEventDisableTiming));
         c->aux_made = true;
     }
     hipStream_t aux = overlap ? c->st_aux : st;
@@ -408,7 +427,6 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
         if ((rc = mark(kEvBlur0, aux))) return rc;
         hipLaunchKernelGGL(k_blur7_all, dim3(B.blur_first[L], n), dim3(256), 0, aux, B);
         if ((rc = mark(kEvBlur1, aux))) return rc;
-        HIP_TRY(c, hipEventRecord(c->ev_blur_done, aux));
     }
     // stage 1 (main): FAST cells, level 0 first
     if ((rc = mark(kEvFastA0, st))) return rc;
@@ -423,23 +441,32 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
                        (const uint32_t*)c->d_ccount.p, (uint32_t*)c->d_dense_pts.p, (uint16_t*)c->d_dense_node.p,
                        (uint32_t*)c->d_lvl_kps.p, (int32_t*)c->d_lvl_count.p);
     if ((rc = mark(kEvOct1, st))) return rc;
+    hipStream_t sd = st;  // stream of the descriptor stage
     if (overlap) {
-        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_blur_done, 0));
+        // stage 4 follows the blur on the auxiliary stream once the quadtree has finished; the main
+        // stream is then free for the next batch's FAST (join() orders anything else behind it)
+        HIP_TRY(c, hipEventRecord(c->ev_oct_done, st));
+        HIP_TRY(c, hipStreamWaitEvent(aux, c->ev_oct_done, 0));
+        sd = aux;
     } else {
         if ((rc = mark(kEvBlur0, st))) return rc;
         hipLaunchKernelGGL(k_blur7_all, dim3(B.blur_first[L], n), dim3(256), 0, st, B);
         if ((rc = mark(kEvBlur1, st))) return rc;
     }
-    // stage 4 (main): orientation + descriptors + output assembly
-    if ((rc = mark(kEvDesc0, st))) return rc;
+    // stage 4: orientation + descriptors + output assembly
+    if ((rc = mark(kEvDesc0, sd))) return rc;
     {
         const int kp_blocks = (c->max_kp_level + kDescKp - 1) / kDescKp;
         const unsigned grid = 8u * (unsigned)((n + 7) / 8) * (unsigned)L * (unsigned)kp_blocks;
-        hipLaunchKernelGGL(k_orient_describe, dim3(grid), dim3(256), 0, st, B, (const uint32_t*)c->d_lvl_kps.p,
+        hipLaunchKernelGGL(k_orient_describe, dim3(grid), dim3(256), 0, sd, B, (const uint32_t*)c->d_lvl_kps.p,
                            (const int32_t*)c->d_lvl_count.p, (const int8_t*)c->d_pat.p, d_kps, d_desc, d_n_out, kp_cap,
                            kp_blocks);
     }
-    if ((rc = mark(kEvDesc1, st))) return rc;
+    if ((rc = mark(kEvDesc1, sd))) return rc;
+    if (overlap) {
+        HIP_TRY(c, hipEventRecord(c->ev_desc_done, aux));
+        c->desc_pending = true;
+    }
     if (prof) c->ev_valid = true;
     HIP_TRY(c, hipGetLastError());
     c->have_last = true;
@@ -572,6 +599,7 @@ int extract_batch_pipelined(orbx_ctx* c, int n, const uint8_t* const* imgs, int 
     const size_t res_kps = (size_t)m * cap * sizeof(orbx_kp), res_desc = (size_t)m * cap * 32, res_cnt = (size_t)m * 4;
     int rc = ensure_pipeline(c, (size_t)m * plane, res_kps + res_desc + res_cnt);
     if (rc) return rc;
+    if ((rc = sync_ctx(c))) return rc;  // nothing of an earlier call is still in flight
     const int host_threads = (int)std::max(1u, std::min(4u, std::thread::hardware_concurrency()));
     const int nchunks = (n + m - 1) / m;
     orbx_kp* d_kps = (orbx_kp*)c->d_out_kps.p;
@@ -610,7 +638,7 @@ int extract_batch_pipelined(orbx_ctx* c, int n, const uint8_t* const* imgs, int 
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_up[slot], 0));
         rc = run_batch(c, mk, nullptr, 0, 0, d_kps + (size_t)f0 * cap, cap, d_desc + (size_t)f0 * cap * 32, d_cnt + f0, n, f0);
         if (rc) return rc;
-        HIP_TRY(c, hipEventRecord(c->ev_done[slot], c->stream));
+        HIP_TRY(c, hipEventRecord(c->ev_done[slot], c->desc_pending ? c->st_aux : c->stream));  // after the descriptors
         // the result slot of chunk k-2 was consumed before chunk k-1 was enqueued (below)
         HIP_TRY(c, hipStreamWaitEvent(c->st_down, c->ev_done[slot], 0));
         uint8_t* res = (uint8_t*)c->h_res[slot];
@@ -623,7 +651,7 @@ int extract_batch_pipelined(orbx_ctx* c, int n, const uint8_t* const* imgs, int 
         if (k >= 1 && (rc = consume(k - 1))) return rc;
     }
     if ((rc = consume(nchunks - 1))) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     fill_batch(c, n, nullptr, 0, 0, n, 0);  // read-backs and the stereo stage see the whole batch
     c->last_kps = d_kps;
     c->last_desc = d_desc;
@@ -688,7 +716,7 @@ extern "C" int orbx_create(const orbx_params* params, orbx_ctx** out) {
 extern "C" void orbx_destroy(orbx_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->prm.device_id);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)sync_ctx(c);
 #ifdef ORBX_STAMPS
     if (c->d_stamps.p) {
         std::vector<unsigned long long> h(1024 * 16);
@@ -713,7 +741,8 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
     if (c->aux_made) {
         (void)hipEventDestroy(c->ev_start);
         (void)hipEventDestroy(c->ev_pyr_done);
-        (void)hipEventDestroy(c->ev_blur_done);
+        (void)hipEventDestroy(c->ev_oct_done);
+        (void)hipEventDestroy(c->ev_desc_done);
         (void)hipStreamDestroy(c->st_aux);
     }
     if (c->pipe_made) {
@@ -744,6 +773,7 @@ extern "C" int orbx_extract_batch_device(orbx_ctx* c, int n, const uint8_t* d_im
     const bool in_place = ((uintptr_t)d_imgs % 4 == 0) && (stride % 4 == 0) && (frame_stride % 4 == 0);
     if ((rc = ensure_arenas(c, n, !in_place))) return rc;
     if (!in_place) {
+        if ((rc = join(c))) return rc;  // level 0 of the arena is still read by the previous batch's descriptors
         for (int i = 0; i < n; ++i)
             HIP_TRY(c, hipMemcpy2DAsync((uint8_t*)c->d_pyr.p + (size_t)i * c->plane[0], c->pitch[0],
                                         d_imgs + (size_t)i * frame_stride, stride, width, height,
@@ -753,7 +783,7 @@ extern "C" int orbx_extract_batch_device(orbx_ctx* c, int n, const uint8_t* d_im
         rc = run_batch(c, n, d_imgs, stride, frame_stride, d_kps, kp_cap, d_desc, d_n_out);
     }
     if (rc) return rc;
-    if (sync) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     return ORBX_OK;
 }
 
@@ -782,10 +812,11 @@ extern "C" int orbx_extract_batch(orbx_ctx* c, int n, const uint8_t* const* imgs
     rc = run_batch(c, n, nullptr, 0, 0, (orbx_kp*)c->d_out_kps.p, cap, (uint8_t*)c->d_out_desc.p,
                    (int32_t*)c->d_out_n.p);
     if (rc) return rc;
+    if ((rc = join(c))) return rc;
     const double t_c = now();
     std::vector<int32_t> cnt(n);
     HIP_TRY(c, hipMemcpyAsync(cnt.data(), c->d_out_n.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     const double t_d = now();
     for (int i = 0; i < n; ++i) {
         const int k = cnt[i];
@@ -797,7 +828,7 @@ extern "C" int orbx_extract_batch(orbx_ctx* c, int n, const uint8_t* const* imgs
                                       (size_t)k * 32, hipMemcpyDeviceToHost, c->stream));
         }
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     if (trace)
         std::fprintf(stderr, "orbx_extract_batch host ms: upload-enqueue %.3f launch %.3f wait+counts %.3f download %.3f\n",
                      t_b - t_a, t_c - t_b, t_d - t_c, now() - t_d);
@@ -819,11 +850,13 @@ extern "C" int orbx_stereo_match_batch_device(orbx_ctx* c, int n_pairs, const or
     if (!c->have_last) return ORBX_E_STATE;
     if (2 * n_pairs > c->B.nframes || kp_cap > 65535) return ORBX_E_CAPACITY;
     HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    int rc = join(c);  // the descriptors of the batch may still be running on the auxiliary stream
+    if (rc) return rc;
     // pair p = images (2p, 2p + 1) of the last batch; their results are 2 * kp_cap keypoints apart
-    int rc = run_stereo(c, c, n_pairs, 0, 1, 2, d_kps, d_kps + kp_cap, d_desc, d_desc + (size_t)kp_cap * 32, d_n, d_n + 1,
+    rc = run_stereo(c, c, n_pairs, 0, 1, 2, d_kps, d_kps + kp_cap, d_desc, d_desc + (size_t)kp_cap * 32, d_n, d_n + 1,
                         2 * (int64_t)kp_cap, 2, kp_cap, mb, mbf, d_u_right, d_depth);
     if (rc) return rc;
-    if (sync) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     return ORBX_OK;
 }
 
@@ -839,7 +872,7 @@ extern "C" int orbx_stereo_match(orbx_ctx* left, int img_left, orbx_ctx* right, 
         left->prm.scale_factor != right->prm.scale_factor || left->last_kp_cap != right->last_kp_cap)
         return ORBX_E_INVALID;
     HIP_TRY(left, hipSetDevice(left->prm.device_id));
-    HIP_TRY(left, hipStreamSynchronize(right->stream));  // the right extraction has finished
+    { int rc_ = sync_ctx(right); if (rc_) return rc_; }  // the right extraction has finished
     const int kp_cap = left->last_kp_cap;
     if (kp_cap > 65535) return ORBX_E_CAPACITY;
     int32_t nl = 0;
@@ -852,7 +885,7 @@ extern "C" int orbx_stereo_match(orbx_ctx* left, int img_left, orbx_ctx* right, 
                     right->last_desc + (size_t)img_right * kp_cap * 32, left->last_n + img_left, right->last_n + img_right, 0,
                     0, kp_cap, mb, mbf, (float*)left->d_st_u.p, (float*)left->d_st_depth.p);
     if (rc) return rc;
-    HIP_TRY(left, hipStreamSynchronize(left->stream));
+    { int rc_ = sync_ctx(left); if (rc_) return rc_; }
     *n_left = nl;
     if (nl > cap) return ORBX_E_CAPACITY;
     if (nl > 0) {
@@ -869,6 +902,7 @@ extern "C" int orbx_gray_batch_device(orbx_ctx* c, int n, const uint8_t* d_src, 
     if ((channels != 3 && channels != 4) || (blue_idx != 0 && blue_idx != 2)) return ORBX_E_INVALID;
     if (src_stride < width * channels || dst_stride < width) return ORBX_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    { int rc_ = join(c); if (rc_) return rc_; }  // the destination may be the input of a batch still being described
     const dim3 grid(((width + 3) / 4 + 255) / 256, height, n);
     if (channels == 3)
         hipLaunchKernelGGL(k_cvt_gray<3>, grid, dim3(256), 0, c->stream, d_src, src_stride, (uint64_t)src_frame_stride,
@@ -877,7 +911,7 @@ extern "C" int orbx_gray_batch_device(orbx_ctx* c, int n, const uint8_t* d_src, 
         hipLaunchKernelGGL(k_cvt_gray<4>, grid, dim3(256), 0, c->stream, d_src, src_stride, (uint64_t)src_frame_stride,
                            d_dst, dst_stride, (uint64_t)dst_frame_stride, width, blue_idx);
     HIP_TRY(c, hipGetLastError());
-    if (sync) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     return ORBX_OK;
 }
 
@@ -889,12 +923,13 @@ extern "C" int orbx_remap_batch_device(orbx_ctx* c, int n, const uint8_t* d_src,
     if (src_width < 1 || src_height < 1 || dst_width < 1 || dst_height < 1 || dst_height > 65535) return ORBX_E_INVALID;
     if (src_stride < src_width || dst_stride < dst_width || map_stride < dst_width) return ORBX_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    { int rc_ = join(c); if (rc_) return rc_; }
     const dim3 grid(((dst_width + 3) / 4 + 255) / 256, dst_height, n);
     hipLaunchKernelGGL(k_remap_linear, grid, dim3(256), 0, c->stream, d_src, src_width, src_height, src_stride,
                        (uint64_t)src_frame_stride, d_mapx, d_mapy, map_stride, d_dst, dst_width, dst_stride,
                        (uint64_t)dst_frame_stride);
     HIP_TRY(c, hipGetLastError());
-    if (sync) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     return ORBX_OK;
 }
 
@@ -905,17 +940,18 @@ extern "C" int orbx_undistort_grid_batch_device(orbx_ctx* c, int n, const orbx_k
     if (!c || !d_kps || !d_n || !K || !dist || !d_kps_un || !d_cell_start || !d_cell_idx || n < 1 || kp_cap < 1)
         return ORBX_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    { int rc_ = join(c); if (rc_) return rc_; }
     PostParams P = {K[0], K[1], K[2], K[3], dist[0], dist[1], dist[2], dist[3], dist[4], min_x, min_y, inv_w, inv_h};
     hipLaunchKernelGGL(k_undistort_grid, dim3(n), dim3(256), 0, c->stream, P, d_kps, d_n, kp_cap, d_kps_un, d_cell_start,
                        d_cell_idx);
     HIP_TRY(c, hipGetLastError());
-    if (sync) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     return ORBX_OK;
 }
 
 extern "C" int orbx_synchronize(orbx_ctx* c) {
     if (!c) return ORBX_E_INVALID;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     return ORBX_OK;
 }
 
@@ -927,13 +963,13 @@ extern "C" int orbx_pyramid_level(orbx_ctx* c, int img_idx, int level, uint8_t* 
     const LevelDev& D = c->B.lv[level];
     if (dst_stride < D.w) return ORBX_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->prm.device_id));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     // one contiguous copy into pinned memory, rows re-pitched on the host
     const size_t bytes = (size_t)(D.h - 1) * D.pitch + D.w;
     int rc = ensure_stage(c, bytes);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->h_stage, D.img + (size_t)img_idx * D.plane, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     for (int y = 0; y < D.h; ++y)
         std::memcpy(dst + (size_t)y * dst_stride, (const uint8_t*)c->h_stage + (size_t)y * D.pitch, (size_t)D.w);
     if (width) *width = D.w;
@@ -947,7 +983,7 @@ extern "C" int orbx_debug_read(orbx_ctx* c, int what, int img_idx, int level, vo
     if (!c->have_last) return ORBX_E_STATE;
     if (img_idx < 0 || img_idx >= c->B.nframes || level < 0 || level >= c->B.nlevels) return ORBX_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->prm.device_id));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     const LevelDev& D = c->B.lv[level];
     const BatchDev& B = c->B;
     if (what == ORBX_DBG_BLURRED) {

@@ -211,6 +211,44 @@ def test_full_size_batch_properties(oracle):
     frames.free()
 
 
+def test_back_to_back_async_batches(oracle):
+    """Several batches enqueued without waiting in between (sync=False): the library overlaps a batch's
+    descriptor stage with the next batch's detection on another stream, and its arenas are reused by
+    every batch, so this is the ordering test of that schedule.  Inputs differ per batch, outputs go to
+    separate buffers, everything is compared with the oracle after one final synchronisation."""
+    from hip_rt import DeviceArray
+    w, h, nf, nl, n, nb = 752, 480, 1200, 8, 24, 5
+    stride = 768
+    ex = oa.ORBextractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=n, keep_pyramid=False)
+    cap = ex.max_keypoints(w, h)
+    hosts, d_in, d_out = [], [], []
+    for b in range(nb):
+        host = np.zeros((n, h, stride), np.uint8)
+        host[:, :, :w] = synth.make_batch(n, w, h, 4, 200 + 37 * b)
+        hosts.append(host)
+        d_in.append(DeviceArray.from_host(host))
+        d_out.append((DeviceArray((n, cap, 28), np.uint8, fill_byte=0), DeviceArray((n, cap, 32), np.uint8, fill_byte=0),
+                      DeviceArray((n,), np.int32, fill_byte=0)))
+    for rep in range(2):                                  # twice: the second round starts on warm streams
+        for b in range(nb):
+            k, q, c = d_out[b]
+            ex.extract_batch_device(d_in[b].ptr, n, w, h, stride, h * stride, k.ptr, cap, q.ptr, c.ptr, sync=False)
+    ex.synchronize()
+    orc = oracle.Oracle(nf, 1.2, nl, 20, 7)
+    for b in range(nb):
+        kps, desc, cnt = (a.to_host() for a in d_out[b])
+        for i in (0, 11, n - 1):
+            okps, odesc = orc.extract(hosts[b][i, :, :w])
+            assert cnt[i] == len(okps), (b, i)
+            _check_final(np.ascontiguousarray(kps[i, :cnt[i]]).reshape(-1).view(oa.KP_DTYPE), desc[i, :cnt[i]], okps, odesc)
+    ex.close()
+    for a in d_in:
+        a.free()
+    for t in d_out:
+        for a in t:
+            a.free()
+
+
 def test_errors():
     ex = oa.ORBextractor(500, 1.2, 8, 20, 7, max_width=320, max_height=240)
     with pytest.raises(oa.OrbxError):
