@@ -65,7 +65,13 @@ struct orbx_ctx {
     DevBuf d_cells, d_tiles, d_pat;
     DevBuf d_xt[ORBX_MAX_LEVELS], d_yt[ORBX_MAX_LEVELS];
     // device arenas (grown on demand)
-    DevBuf d_pyr, d_blur, d_cand, d_ccount, d_dense_pts, d_dense_node, d_lvl_kps, d_lvl_count;
+    // Two sets of everything the descriptor stage reads (pyramid, blurred pyramid, retained points):
+    // the descriptors of one batch run while the next batch is detected into the other set.
+    DevBuf d_pyr[2], d_blur[2], d_lvl_kps[2], d_lvl_count[2];
+    DevBuf d_cand, d_ccount, d_dense_pts, d_dense_node;
+    int arena_set = 0, kp_set = 0;            // sets of the last batch
+    int arena_desc[2] = {-1, -1};             // descriptor event (index into ev_desc) last reading each arena set
+    bool desc_pending[2] = {false, false};    // ev_desc[i] recorded and not yet joined
     DevBuf d_out_kps, d_out_desc, d_out_n;  // results of the host-memory entry points
     DevBuf d_stamps;                        // diagnostic builds (-DORBX_STAMPS)
 
@@ -90,9 +96,9 @@ struct orbx_ctx {
     bool pipe_made = false;
     // auxiliary compute stream (pyramid + blur beside FAST + quadtree) and its ordering events
     hipStream_t st_aux = nullptr;
-    hipEvent_t ev_start, ev_pyr_done, ev_oct_done, ev_desc_done;
+    hipStream_t st_desc = nullptr;            // descriptor stage
+    hipEvent_t ev_start, ev_pyr_done, ev_blur_done, ev_oct_done, ev_desc[2];
     bool aux_made = false;
-    bool desc_pending = false;  // the last batch's descriptors may still be running on the auxiliary stream
     int tiles_level0 = 0;  // the first tiles_level0 entries of `tiles` belong to level 0
     // stereo stage scratch (grown on demand)
     DevBuf d_st_rows, d_st_meta, d_st_wmax, d_st_sad, d_st_u, d_st_depth;
@@ -114,13 +120,20 @@ namespace {
         }                                         \
     } while (0)
 
-// The descriptors of a batch run on the auxiliary stream (see run_batch).  join() makes everything
+// The descriptors of a batch run on their own stream (see run_batch).  join() makes everything
 // enqueued on the main stream from here on wait for them; sync_ctx() also drains the main stream.
 int join(orbx_ctx* c) {
-    if (c->desc_pending) {
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_desc_done, 0));
-        c->desc_pending = false;
-    }
+    for (int i = 0; i < 2; ++i)
+        if (c->desc_pending[i]) {
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_desc[i], 0));
+            c->desc_pending[i] = false;
+        }
+    return ORBX_OK;
+}
+// `stream` waits until the descriptor stage that last read arena set `set` has finished.
+int wait_arena_free(orbx_ctx* c, int set, hipStream_t stream) {
+    const int e = c->arena_desc[set];
+    if (e >= 0 && c->desc_pending[e]) HIP_TRY(c, hipStreamWaitEvent(stream, c->ev_desc[e], 0));
     return ORBX_OK;
 }
 int sync_ctx(orbx_ctx* c) {
@@ -269,13 +282,13 @@ int ensure_stage(orbx_ctx* c, size_t bytes) {
 }
 
 // Host images -> level 0 of the pyramid arena (device pitch), through the pinned staging buffer.
-int upload_level0(orbx_ctx* c, int n, const uint8_t* const* imgs, const int* strides, int width, int height) {
+int upload_level0(orbx_ctx* c, int set, int n, const uint8_t* const* imgs, const int* strides, int width, int height) {
     const size_t plane = c->plane[0];
     const int pitch = c->pitch[0];
     const int per_chunk = (int)std::max<size_t>(1, kStageMax / plane);
     int rc = ensure_stage(c, plane * (size_t)std::min(n, per_chunk));
     if (rc) return rc;
-    if ((rc = join(c))) return rc;  // level 0 of the arena is still read by the previous batch's descriptors
+    if ((rc = wait_arena_free(c, set, c->stream))) return rc;  // level 0 of this set may still be read by descriptors
     for (int i0 = 0; i0 < n; i0 += per_chunk) {
         const int m = std::min(per_chunk, n - i0);
         if (i0 > 0) { int rc_ = sync_ctx(c); if (rc_) return rc_; }  // the previous chunk has left the staging buffer
@@ -284,7 +297,7 @@ int upload_level0(orbx_ctx* c, int n, const uint8_t* const* imgs, const int* str
             const uint8_t* s = imgs[i0 + i];
             for (int y = 0; y < height; ++y) std::memcpy(d + (size_t)y * pitch, s + (size_t)y * strides[i0 + i], (size_t)width);
         }
-        HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->d_pyr.p + (size_t)i0 * plane, c->h_stage, (size_t)m * plane,
+        HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->d_pyr[set].p + (size_t)i0 * plane, c->h_stage, (size_t)m * plane,
                                   hipMemcpyHostToDevice, c->stream));
     }
     return ORBX_OK;
@@ -297,20 +310,22 @@ int ensure_arenas(orbx_ctx* c, int n, bool need_level0) {
         blur += c->plane[l] * n;
     }
     int rc;
-    if ((rc = ensure(c, &c->d_pyr, pyr))) return rc;
-    if ((rc = ensure(c, &c->d_blur, blur))) return rc;
+    for (int k = 0; k < 2; ++k) {
+        if ((rc = ensure(c, &c->d_pyr[k], pyr))) return rc;
+        if ((rc = ensure(c, &c->d_blur[k], blur))) return rc;
+        if ((rc = ensure(c, &c->d_lvl_kps[k], (size_t)n * c->kp_total * 4))) return rc;
+        if ((rc = ensure(c, &c->d_lvl_count[k], (size_t)n * c->tab.nlevels * 4))) return rc;
+    }
     if ((rc = ensure(c, &c->d_cand, (size_t)n * c->total_cells * c->cell_cap * 4))) return rc;
     if ((rc = ensure(c, &c->d_ccount, (size_t)n * c->total_cells * 4))) return rc;
     if ((rc = ensure(c, &c->d_dense_pts, (size_t)n * c->dense_total * 4))) return rc;
     if ((rc = ensure(c, &c->d_dense_node, (size_t)n * c->dense_total * 2))) return rc;
-    if ((rc = ensure(c, &c->d_lvl_kps, (size_t)n * c->kp_total * 4))) return rc;
-    if ((rc = ensure(c, &c->d_lvl_count, (size_t)n * c->tab.nlevels * 4))) return rc;
     return ORBX_OK;
 }
 
 // Describes n frames in c->B: frames frame0 .. frame0+n-1 of arenas laid out for n_total frames
 // (level-major), level 0 at (l0, l0_pitch, l0_plane) when given, else in the pyramid arena too.
-void fill_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_plane, int n_total, int frame0) {
+void fill_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_plane, int n_total, int frame0, int set) {
     const int L = c->tab.nlevels;
     BatchDev& B = c->B;
     std::memset(&B, 0, sizeof(B));
@@ -337,12 +352,12 @@ void fill_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_p
             D.pitch = l0_pitch;
             D.plane = l0_plane;
         } else {
-            D.img = (const uint8_t*)c->d_pyr.p + poff + c->plane[l] * (size_t)frame0;
+            D.img = (const uint8_t*)c->d_pyr[set].p + poff + c->plane[l] * (size_t)frame0;
             D.pitch = c->pitch[l];
             D.plane = c->plane[l];
             poff += c->plane[l] * n_total;
         }
-        D.blur = (uint8_t*)c->d_blur.p + boff + c->plane[l] * (size_t)frame0;
+        D.blur = (uint8_t*)c->d_blur[set].p + boff + c->plane[l] * (size_t)frame0;
         D.bpitch = c->pitch[l];
         D.bplane = c->plane[l];
         boff += c->plane[l] * n_total;
@@ -369,15 +384,20 @@ void fill_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_p
 
 // Enqueues the whole path for n frames (see fill_batch) on the context's stream.
 int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_plane, orbx_kp* d_kps, int kp_cap,
-              uint8_t* d_desc, int32_t* d_n_out, int n_total = -1, int frame0 = 0) {
-    fill_batch(c, n, l0, l0_pitch, l0_plane, n_total < 0 ? n : n_total, frame0);
+              uint8_t* d_desc, int32_t* d_n_out, int arena_set, int kp_set, int n_total = -1, int frame0 = 0,
+              bool arena_known_free = false) {
+    fill_batch(c, n, l0, l0_pitch, l0_plane, n_total < 0 ? n : n_total, frame0, arena_set);
+    c->arena_set = arena_set;
+    c->kp_set = kp_set;
     const int L = c->tab.nlevels;
     BatchDev& B = c->B;
-    // Two streams.  The auxiliary (low-priority) stream builds the pyramid and then blurs it; the
-    // main stream runs FAST on level 0 (which needs no pyramid) at once, FAST on the other levels
-    // when the pyramid is there, the quadtree, and the descriptors once the blur has finished.
-    // The memory-bound pyramid and blur so fill what the VALU-bound FAST and the latency-bound
-    // quadtree leave idle.  ORBX_NO_OVERLAP=1 puts everything on the main stream in stage order.
+    // Three streams.  The main stream runs FAST on level 0 (which needs no pyramid) at once, FAST on
+    // the other levels when the pyramid is there, and the quadtree.  The auxiliary (low-priority)
+    // stream builds the pyramid and blurs it.  The descriptor stream runs the last stage once the
+    // quadtree and the blur have finished.  The memory-bound pyramid and blur so fill what the
+    // VALU-bound FAST and the latency-bound quadtree leave idle, and the next batch, which works in
+    // the other set of arenas, is detected while this one is described.
+    // ORBX_NO_OVERLAP=1 puts everything on the main stream in stage order.
     const bool overlap = std::getenv("ORBX_NO_OVERLAP") == nullptr;
     hipStream_t st = c->stream;
     if (overlap && !c->aux_made) {
@@ -386,8 +406,11 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
         HIP_TRY(c, hipStreamCreateWithPriority(&c->st_aux, hipStreamNonBlocking, prio_lo));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pyr_done, hipEventDisableTiming));
+        HIP_TRY(c, hipStreamCreateWithPriority(&c->st_desc, hipStreamNonBlocking, prio_lo));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_blur_done, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_oct_done, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_desc_done, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_desc[0], hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_desc[1], hipEventDisableTiming));
         c->aux_made = true;
     }
     hipStream_t aux = overlap ? c->st_aux : st;
@@ -408,6 +431,8 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
         // level 0 and the arenas are ready when the main stream gets here
         HIP_TRY(c, hipEventRecord(c->ev_start, st));
         HIP_TRY(c, hipStreamWaitEvent(aux, c->ev_start, 0));
+        // the pyramid and the blur overwrite this arena set: its last reader must have finished
+        if (!arena_known_free && (rc = wait_arena_free(c, arena_set, aux))) return rc;
     }
     // stage 0 (aux): pyramid
     if ((rc = mark(kEvPyr0, aux))) return rc;
@@ -427,6 +452,7 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
         if ((rc = mark(kEvBlur0, aux))) return rc;
         hipLaunchKernelGGL(k_blur7_all, dim3(B.blur_first[L], n), dim3(256), 0, aux, B);
         if ((rc = mark(kEvBlur1, aux))) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev_blur_done, aux));
     }
     // stage 1 (main): FAST cells, level 0 first
     if ((rc = mark(kEvFastA0, st))) return rc;
@@ -436,18 +462,21 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     if ((rc = mark(kEvFastB0, st))) return rc;
     launch_fast(overlap ? n_tiles0 : 0, overlap ? n_tiles - n_tiles0 : n_tiles);
     if ((rc = mark(kEvFastB1, st))) return rc;
-    // stage 2 (main): quadtree retention
+    // stage 2 (main): quadtree retention; it overwrites the retained points of set kp_set, which the
+    // descriptor stage of the batch before the previous one may still be reading
+    if (overlap && c->desc_pending[kp_set]) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_desc[kp_set], 0));
     hipLaunchKernelGGL(k_octree, dim3(L, n), dim3(256), c->oct_lds, st, B, (const uint32_t*)c->d_cand.p,
                        (const uint32_t*)c->d_ccount.p, (uint32_t*)c->d_dense_pts.p, (uint16_t*)c->d_dense_node.p,
-                       (uint32_t*)c->d_lvl_kps.p, (int32_t*)c->d_lvl_count.p);
+                       (uint32_t*)c->d_lvl_kps[kp_set].p, (int32_t*)c->d_lvl_count[kp_set].p);
     if ((rc = mark(kEvOct1, st))) return rc;
     hipStream_t sd = st;  // stream of the descriptor stage
     if (overlap) {
-        // stage 4 follows the blur on the auxiliary stream once the quadtree has finished; the main
-        // stream is then free for the next batch's FAST (join() orders anything else behind it)
+        // stage 4 on its own stream, after the quadtree and the blur; the other streams are then free
+        // for the next batch (join() orders anything that needs this batch's results behind it)
+        sd = c->st_desc;
         HIP_TRY(c, hipEventRecord(c->ev_oct_done, st));
-        HIP_TRY(c, hipStreamWaitEvent(aux, c->ev_oct_done, 0));
-        sd = aux;
+        HIP_TRY(c, hipStreamWaitEvent(sd, c->ev_oct_done, 0));
+        HIP_TRY(c, hipStreamWaitEvent(sd, c->ev_blur_done, 0));
     } else {
         if ((rc = mark(kEvBlur0, st))) return rc;
         hipLaunchKernelGGL(k_blur7_all, dim3(B.blur_first[L], n), dim3(256), 0, st, B);
@@ -458,14 +487,15 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     {
         const int kp_blocks = (c->max_kp_level + kDescKp - 1) / kDescKp;
         const unsigned grid = 8u * (unsigned)((n + 7) / 8) * (unsigned)L * (unsigned)kp_blocks;
-        hipLaunchKernelGGL(k_orient_describe, dim3(grid), dim3(256), 0, sd, B, (const uint32_t*)c->d_lvl_kps.p,
-                           (const int32_t*)c->d_lvl_count.p, (const int8_t*)c->d_pat.p, d_kps, d_desc, d_n_out, kp_cap,
+        hipLaunchKernelGGL(k_orient_describe, dim3(grid), dim3(256), 0, sd, B, (const uint32_t*)c->d_lvl_kps[kp_set].p,
+                           (const int32_t*)c->d_lvl_count[kp_set].p, (const int8_t*)c->d_pat.p, d_kps, d_desc, d_n_out, kp_cap,
                            kp_blocks);
     }
     if ((rc = mark(kEvDesc1, sd))) return rc;
     if (overlap) {
-        HIP_TRY(c, hipEventRecord(c->ev_desc_done, aux));
-        c->desc_pending = true;
+        HIP_TRY(c, hipEventRecord(c->ev_desc[kp_set], sd));
+        c->desc_pending[kp_set] = true;
+        c->arena_desc[arena_set] = kp_set;
     }
     if (prof) c->ev_valid = true;
     HIP_TRY(c, hipGetLastError());
@@ -600,6 +630,7 @@ int extract_batch_pipelined(orbx_ctx* c, int n, const uint8_t* const* imgs, int 
     int rc = ensure_pipeline(c, (size_t)m * plane, res_kps + res_desc + res_cnt);
     if (rc) return rc;
     if ((rc = sync_ctx(c))) return rc;  // nothing of an earlier call is still in flight
+    const int aset = c->arena_set ^ 1;
     const int host_threads = (int)std::max(1u, std::min(4u, std::thread::hardware_concurrency()));
     const int nchunks = (n + m - 1) / m;
     orbx_kp* d_kps = (orbx_kp*)c->d_out_kps.p;
@@ -632,13 +663,15 @@ int extract_batch_pipelined(orbx_ctx* c, int n, const uint8_t* const* imgs, int 
             const int st = strides[f0 + i];
             for (int y = 0; y < height; ++y) std::memcpy(d + (size_t)y * pitch, s + (size_t)y * st, (size_t)width);
         });
-        HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->d_pyr.p + (size_t)f0 * plane, up, (size_t)mk * plane, hipMemcpyHostToDevice,
+        HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->d_pyr[aset].p + (size_t)f0 * plane, up, (size_t)mk * plane, hipMemcpyHostToDevice,
                                   c->st_up));
         HIP_TRY(c, hipEventRecord(c->ev_up[slot], c->st_up));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_up[slot], 0));
-        rc = run_batch(c, mk, nullptr, 0, 0, d_kps + (size_t)f0 * cap, cap, d_desc + (size_t)f0 * cap * 32, d_cnt + f0, n, f0);
+        // every chunk works in the same arena set (different frames of it) and alternates the retained-point set
+        rc = run_batch(c, mk, nullptr, 0, 0, d_kps + (size_t)f0 * cap, cap, d_desc + (size_t)f0 * cap * 32, d_cnt + f0, aset,
+                       k & 1, n, f0, true);
         if (rc) return rc;
-        HIP_TRY(c, hipEventRecord(c->ev_done[slot], c->desc_pending ? c->st_aux : c->stream));  // after the descriptors
+        HIP_TRY(c, hipEventRecord(c->ev_done[slot], c->desc_pending[k & 1] ? c->st_desc : c->stream));  // after the descriptors
         // the result slot of chunk k-2 was consumed before chunk k-1 was enqueued (below)
         HIP_TRY(c, hipStreamWaitEvent(c->st_down, c->ev_done[slot], 0));
         uint8_t* res = (uint8_t*)c->h_res[slot];
@@ -652,7 +685,7 @@ int extract_batch_pipelined(orbx_ctx* c, int n, const uint8_t* const* imgs, int 
     }
     if ((rc = consume(nchunks - 1))) return rc;
     { int rc_ = sync_ctx(c); if (rc_) return rc_; }
-    fill_batch(c, n, nullptr, 0, 0, n, 0);  // read-backs and the stereo stage see the whole batch
+    fill_batch(c, n, nullptr, 0, 0, n, 0, aset);  // read-backs and the stereo stage see the whole batch
     c->last_kps = d_kps;
     c->last_desc = d_desc;
     c->last_n = d_cnt;
@@ -728,8 +761,9 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
             }
     }
 #endif
-    DevBuf* bufs[] = {&c->d_cells, &c->d_tiles, &c->d_pat, &c->d_pyr, &c->d_blur, &c->d_cand, &c->d_ccount,
-                      &c->d_dense_pts, &c->d_dense_node, &c->d_lvl_kps, &c->d_lvl_count, &c->d_out_kps,
+    DevBuf* bufs[] = {&c->d_cells, &c->d_tiles, &c->d_pat, &c->d_pyr[0], &c->d_pyr[1], &c->d_blur[0], &c->d_blur[1],
+                      &c->d_cand, &c->d_ccount, &c->d_dense_pts, &c->d_dense_node, &c->d_lvl_kps[0], &c->d_lvl_kps[1],
+                      &c->d_lvl_count[0], &c->d_lvl_count[1], &c->d_out_kps,
                       &c->d_out_desc, &c->d_out_n, &c->d_stamps, &c->d_st_rows, &c->d_st_meta, &c->d_st_wmax,
                       &c->d_st_sad, &c->d_st_u, &c->d_st_depth};
     for (DevBuf* b : bufs) release(b);
@@ -741,8 +775,11 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
     if (c->aux_made) {
         (void)hipEventDestroy(c->ev_start);
         (void)hipEventDestroy(c->ev_pyr_done);
+        (void)hipEventDestroy(c->ev_blur_done);
         (void)hipEventDestroy(c->ev_oct_done);
-        (void)hipEventDestroy(c->ev_desc_done);
+        (void)hipEventDestroy(c->ev_desc[0]);
+        (void)hipEventDestroy(c->ev_desc[1]);
+        (void)hipStreamDestroy(c->st_desc);
         (void)hipStreamDestroy(c->st_aux);
     }
     if (c->pipe_made) {
@@ -772,15 +809,16 @@ extern "C" int orbx_extract_batch_device(orbx_ctx* c, int n, const uint8_t* d_im
     if (rc) return rc;
     const bool in_place = ((uintptr_t)d_imgs % 4 == 0) && (stride % 4 == 0) && (frame_stride % 4 == 0);
     if ((rc = ensure_arenas(c, n, !in_place))) return rc;
+    const int aset = c->arena_set ^ 1, kset = c->kp_set ^ 1;
     if (!in_place) {
-        if ((rc = join(c))) return rc;  // level 0 of the arena is still read by the previous batch's descriptors
+        if ((rc = wait_arena_free(c, aset, c->stream))) return rc;  // level 0 of this set may still be read by descriptors
         for (int i = 0; i < n; ++i)
-            HIP_TRY(c, hipMemcpy2DAsync((uint8_t*)c->d_pyr.p + (size_t)i * c->plane[0], c->pitch[0],
+            HIP_TRY(c, hipMemcpy2DAsync((uint8_t*)c->d_pyr[aset].p + (size_t)i * c->plane[0], c->pitch[0],
                                         d_imgs + (size_t)i * frame_stride, stride, width, height,
                                         hipMemcpyDeviceToDevice, c->stream));
-        rc = run_batch(c, n, nullptr, 0, 0, d_kps, kp_cap, d_desc, d_n_out);
+        rc = run_batch(c, n, nullptr, 0, 0, d_kps, kp_cap, d_desc, d_n_out, aset, kset);
     } else {
-        rc = run_batch(c, n, d_imgs, stride, frame_stride, d_kps, kp_cap, d_desc, d_n_out);
+        rc = run_batch(c, n, d_imgs, stride, frame_stride, d_kps, kp_cap, d_desc, d_n_out, aset, kset);
     }
     if (rc) return rc;
     if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
@@ -807,10 +845,11 @@ extern "C" int orbx_extract_batch(orbx_ctx* c, int n, const uint8_t* const* imgs
         if (trace) std::fprintf(stderr, "orbx_extract_batch (pipelined) host ms: %.3f\n", now() - t_a);
         return rc;
     }
-    if ((rc = upload_level0(c, n, imgs, strides, width, height))) return rc;
+    const int aset = c->arena_set ^ 1, kset = c->kp_set ^ 1;
+    if ((rc = upload_level0(c, aset, n, imgs, strides, width, height))) return rc;
     const double t_b = now();
     rc = run_batch(c, n, nullptr, 0, 0, (orbx_kp*)c->d_out_kps.p, cap, (uint8_t*)c->d_out_desc.p,
-                   (int32_t*)c->d_out_n.p);
+                   (int32_t*)c->d_out_n.p, aset, kset);
     if (rc) return rc;
     if ((rc = join(c))) return rc;
     const double t_c = now();
@@ -1014,12 +1053,12 @@ extern "C" int orbx_debug_read(orbx_ctx* c, int what, int img_idx, int level, vo
     }
     if (what == ORBX_DBG_LEVEL_KPS) {
         int32_t n = 0;
-        HIP_TRY(c, hipMemcpy(&n, (int32_t*)c->d_lvl_count.p + (size_t)img_idx * B.nlevels + level, 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(&n, (int32_t*)c->d_lvl_count[c->kp_set].p + (size_t)img_idx * B.nlevels + level, 4, hipMemcpyDeviceToHost));
         *n_bytes = (size_t)n * 12;
         if (cap_bytes < *n_bytes) return ORBX_E_CAPACITY;
         std::vector<uint32_t> v(n);
         if (n)
-            HIP_TRY(c, hipMemcpy(v.data(), (uint32_t*)c->d_lvl_kps.p + (size_t)img_idx * B.kp_total + D.kp_off,
+            HIP_TRY(c, hipMemcpy(v.data(), (uint32_t*)c->d_lvl_kps[c->kp_set].p + (size_t)img_idx * B.kp_total + D.kp_off,
                                  (size_t)n * 4, hipMemcpyDeviceToHost));
         int32_t* o = (int32_t*)dst;
         for (int i = 0; i < n; ++i) {
