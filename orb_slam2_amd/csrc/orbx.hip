@@ -97,7 +97,7 @@ struct orbx_ctx {
     // auxiliary compute stream (pyramid + blur beside FAST + quadtree) and its ordering events
     hipStream_t st_aux = nullptr;
     hipStream_t st_desc = nullptr;            // descriptor stage
-    hipEvent_t ev_start, ev_pyr_done, ev_blur_done, ev_oct_done, ev_desc[2];
+    hipEvent_t ev_start, ev_pyr_done, ev_fast_done, ev_blur_done, ev_oct_done, ev_desc[2];
     bool aux_made = false;
     int tiles_level0 = 0;  // the first tiles_level0 entries of `tiles` belong to level 0
     // stereo stage scratch (grown on demand)
@@ -392,7 +392,7 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     const int L = c->tab.nlevels;
     BatchDev& B = c->B;
     // Three streams.  The main stream runs FAST on level 0 (which needs no pyramid) at once, FAST on
-    // the other levels when the pyramid is there, and the quadtree.  The auxiliary (low-priority)
+    // the other levels when the pyramid is there, and the quadtree.  The auxiliary
     // stream builds the pyramid and blurs it.  The descriptor stream runs the last stage once the
     // quadtree and the blur have finished.  The memory-bound pyramid and blur so fill what the
     // VALU-bound FAST and the latency-bound quadtree leave idle, and the next batch, which works in
@@ -401,13 +401,14 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     const bool overlap = std::getenv("ORBX_NO_OVERLAP") == nullptr;
     hipStream_t st = c->stream;
     if (overlap && !c->aux_made) {
-        int prio_lo = 0, prio_hi = 0;
-        HIP_TRY(c, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        HIP_TRY(c, hipStreamCreateWithPriority(&c->st_aux, hipStreamNonBlocking, prio_lo));
+        // All streams at the default priority: with low-priority streams a wait on one of them from a
+        // default-priority stream stalled for tens of seconds (measured with the chunked host path).
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->st_aux, hipStreamNonBlocking));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pyr_done, hipEventDisableTiming));
-        HIP_TRY(c, hipStreamCreateWithPriority(&c->st_desc, hipStreamNonBlocking, prio_lo));
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->st_desc, hipStreamNonBlocking));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_blur_done, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fast_done, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_oct_done, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_desc[0], hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_desc[1], hipEventDisableTiming));
@@ -448,11 +449,6 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     if ((rc = mark(kEvPyr1, aux))) return rc;
     if (overlap) {
         HIP_TRY(c, hipEventRecord(c->ev_pyr_done, aux));
-        // stage 3 (aux): blur of all levels, behind the pyramid on the same stream
-        if ((rc = mark(kEvBlur0, aux))) return rc;
-        hipLaunchKernelGGL(k_blur7_all, dim3(B.blur_first[L], n), dim3(256), 0, aux, B);
-        if ((rc = mark(kEvBlur1, aux))) return rc;
-        HIP_TRY(c, hipEventRecord(c->ev_blur_done, aux));
     }
     // stage 1 (main): FAST cells, level 0 first
     if ((rc = mark(kEvFastA0, st))) return rc;
@@ -462,6 +458,17 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     if ((rc = mark(kEvFastB0, st))) return rc;
     launch_fast(overlap ? n_tiles0 : 0, overlap ? n_tiles - n_tiles0 : n_tiles);
     if ((rc = mark(kEvFastB1, st))) return rc;
+    if (overlap) {
+        // stage 3 (aux): blur of all levels.  It is held back until FAST has finished: started earlier
+        // it only slows FAST down (both are bound by vector instruction issue), started here it runs
+        // beside the quadtree and the descriptor stage, which leave the vector units idle.
+        HIP_TRY(c, hipEventRecord(c->ev_fast_done, st));
+        HIP_TRY(c, hipStreamWaitEvent(aux, c->ev_fast_done, 0));
+        if ((rc = mark(kEvBlur0, aux))) return rc;
+        hipLaunchKernelGGL(k_blur7_all, dim3(B.blur_first[L], n), dim3(256), 0, aux, B);
+        if ((rc = mark(kEvBlur1, aux))) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev_blur_done, aux));
+    }
     // stage 2 (main): quadtree retention; it overwrites the retained points of set kp_set, which the
     // descriptor stage of the batch before the previous one may still be reading
     if (overlap && c->desc_pending[kp_set]) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_desc[kp_set], 0));
@@ -653,9 +660,14 @@ int extract_batch_pipelined(orbx_ctx* c, int n, const uint8_t* const* imgs, int 
         return ORBX_OK;
     };
 
+    const bool ptrace = std::getenv("ORBX_TRACE") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tp0 = tnow();
     for (int k = 0; k < nchunks; ++k) {
         const int slot = k & 1, f0 = k * m, mk = std::min(m, n - f0);
+        if (ptrace) std::fprintf(stderr, "chunk %d start %.3f\n", k, tnow() - tp0);
         if (k >= 2) HIP_TRY(c, hipEventSynchronize(c->ev_up[slot]));  // upload slot free again
+        if (ptrace) std::fprintf(stderr, "chunk %d slot free %.3f\n", k, tnow() - tp0);
         uint8_t* up = (uint8_t*)c->h_up[slot];
         parallel_for(mk, host_threads, [&](int i) {
             uint8_t* d = up + (size_t)i * plane;
@@ -681,7 +693,9 @@ int extract_batch_pipelined(orbx_ctx* c, int n, const uint8_t* const* imgs, int 
                                   c->st_down));
         HIP_TRY(c, hipMemcpyAsync(res + res_kps + res_desc, d_cnt + f0, (size_t)mk * 4, hipMemcpyDeviceToHost, c->st_down));
         HIP_TRY(c, hipEventRecord(c->ev_down[slot], c->st_down));
+        if (ptrace) std::fprintf(stderr, "chunk %d enqueued %.3f\n", k, tnow() - tp0);
         if (k >= 1 && (rc = consume(k - 1))) return rc;
+        if (ptrace) std::fprintf(stderr, "chunk %d consumed prev %.3f\n", k, tnow() - tp0);
     }
     if ((rc = consume(nchunks - 1))) return rc;
     { int rc_ = sync_ctx(c); if (rc_) return rc_; }
@@ -776,6 +790,7 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
         (void)hipEventDestroy(c->ev_start);
         (void)hipEventDestroy(c->ev_pyr_done);
         (void)hipEventDestroy(c->ev_blur_done);
+        (void)hipEventDestroy(c->ev_fast_done);
         (void)hipEventDestroy(c->ev_oct_done);
         (void)hipEventDestroy(c->ev_desc[0]);
         (void)hipEventDestroy(c->ev_desc[1]);
