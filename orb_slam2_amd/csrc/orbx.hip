@@ -592,7 +592,7 @@ void parallel_for(int n, int threads, F fn) {
 }
 
 constexpr int kPipeMinFrames = 16;            // smaller batches take the single-shot path
-constexpr size_t kPipeChunkBytes = (size_t)24 << 20;  // level-0 bytes per chunk
+constexpr size_t kPipeChunkBytes = (size_t)32 << 20;  // level-0 bytes per chunk
 
 int ensure_pipeline(orbx_ctx* c, size_t up_bytes, size_t res_bytes) {
     if (!c->pipe_made) {
