@@ -249,6 +249,58 @@ def test_back_to_back_async_batches(oracle):
             a.free()
 
 
+@pytest.mark.parametrize("w,h,nf,scale,nl,ini,mn,cid", [
+    (200, 150, 50, 1.2, 1, 20, 7, 11),        # one level, tiny quota
+    (255, 193, 300, 1.5, 3, 20, 7, 12),       # coarse scale factor, odd sizes
+    (512, 512, 700, 2.0, 4, 20, 7, 13),       # scale 2, square image (one quadtree root)
+    (1000, 130, 400, 1.2, 4, 20, 7, 14),      # very wide strip: seven or eight quadtree roots
+    (640, 480, 1000, 1.2, 8, 12, 12, 15),     # equal thresholds: the retry finds nothing new
+    (640, 480, 1000, 1.2, 8, 60, 30, 16),     # high thresholds: many cells stay empty, quotas not reached
+    (640, 480, 5000, 1.1, 12, 20, 7, 17),     # fine scale factor, 12 levels, quota above the candidate count
+    (131, 119, 100, 1.2, 4, 20, 7, 18),       # top level just above the 62-px limit of the cell grid
+])
+def test_parameter_space(oracle, w, h, nf, scale, nl, ini, mn, cid):
+    img = synth.make_frame(w, h, cid, 1)
+    ex = oa.ORBextractor(nf, scale, nl, ini, mn, max_width=w, max_height=h)
+    orc = oracle.Oracle(nf, scale, nl, ini, mn)
+    kps, desc = ex(img)
+    okps, odesc = orc.extract(img)
+    _check_stages(ex, orc, img)
+    _check_final(kps, desc, okps, odesc)
+    assert len(kps) > 0
+    ex.close()
+
+
+def test_device_input_unaligned(oracle):
+    """Device-resident input whose pointer, stride and frame stride are not multiples of 4: the library
+    cannot use it in place and copies it into its arena first."""
+    from hip_rt import DeviceArray
+    w, h, nf, nl, n = 641, 479, 1000, 8, 3
+    stride, fstride, lead = 645, 645 * 479 + 7, 3
+    imgs = synth.make_batch(n, w, h, 1, 300)
+    raw = np.zeros(lead + n * fstride, np.uint8)
+    for i in range(n):
+        view = raw[lead + i * fstride: lead + i * fstride + h * stride].reshape(h, stride)
+        view[:, :w] = imgs[i]
+    d_raw = DeviceArray.from_host(raw)
+    ex = oa.ORBextractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=n)
+    cap = ex.max_keypoints(w, h)
+    d_kps, d_desc = DeviceArray((n, cap, 28), np.uint8, fill_byte=0), DeviceArray((n, cap, 32), np.uint8, fill_byte=0)
+    d_n = DeviceArray((n,), np.int32, fill_byte=0)
+    for rep in range(2):
+        ex.extract_batch_device(d_raw.ptr + lead, n, w, h, stride, fstride, d_kps.ptr, cap, d_desc.ptr, d_n.ptr, sync=True)
+    cnt, kps, desc = d_n.to_host(), d_kps.to_host(), d_desc.to_host()
+    orc = oracle.Oracle(nf, 1.2, nl, 20, 7)
+    for i in range(n):
+        okps, odesc = orc.extract(imgs[i])
+        assert cnt[i] == len(okps)
+        _check_final(np.ascontiguousarray(kps[i, :cnt[i]]).reshape(-1).view(oa.KP_DTYPE), desc[i, :cnt[i]], okps, odesc)
+    assert (ex.pyramid_level(2, 0) == imgs[2]).all()
+    ex.close()
+    for a in (d_raw, d_kps, d_desc, d_n):
+        a.free()
+
+
 def test_errors():
     ex = oa.ORBextractor(500, 1.2, 8, 20, 7, max_width=320, max_height=240)
     with pytest.raises(oa.OrbxError):
