@@ -183,8 +183,9 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
             const uint32_t Cd = *reinterpret_cast<const uint32_t*>(pc);
             const uint32_t Ud = *reinterpret_cast<const uint32_t*>(pc + 3 * TP);
             const uint32_t Dd = *reinterpret_cast<const uint32_t*>(pc - 3 * TP);
-            const uint32_t Rd = *reinterpret_cast<const u32_unaligned*>(pc + 3);
-            const uint32_t Ld = *reinterpret_cast<const u32_unaligned*>(pc - 3);
+            // pixels +3 / -3: aligned neighbour dwords shifted into place (unaligned LDS reads are slow)
+            const uint32_t Rd = __builtin_amdgcn_alignbyte(*reinterpret_cast<const uint32_t*>(pc + 4), Cd, 3);
+            const uint32_t Ld = __builtin_amdgcn_alignbyte(Cd, *reinterpret_cast<const uint32_t*>(pc - 4), 1);
             uint32_t on[2] = {0x80008000u, 0x80008000u};
             if (RETRY) {
 #pragma unroll

@@ -19,6 +19,12 @@ namespace orbx {
 // dynamic LDS = resize_lds_bytes(...) (source tile + 256 column taps + 16 row taps).
 constexpr int kRsTW = 256, kRsTH = 16;
 
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t taps, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, taps), c, false);
+}
+
+
 __host__ __device__ inline int resize_src_pitch(int max_col_span) { return ((max_col_span + 15 + 16) & ~15); }
 
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, int spitch, uint64_t splane,
@@ -74,6 +80,20 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 #pragma unroll
     for (int k = 0; k < 4; ++k) tx[k] = s_xt[min(lx + k, ncol - 1)];
     uint8_t* D = dst + (uint64_t)blockIdx.z * dplane + dx_first + lx;
+    // The eight source bytes a row contributes to the thread's four pixels lie within 8 bytes of the
+    // first tap for every scale factor up to 2 (span 3*scale + 2).  They are then fetched as three
+    // aligned dwords and shifted into two; one v_perm_b32 per pixel picks its two taps into the halves of a dword and
+    // one v_dot2_u32_u16 against the packed weights gives S[sx]*a0 + S[sx+1]*a1.
+    const int base = tx[0].ofs;
+    const bool fits = (int)tx[3].ofs1 - base <= 7;
+    const int base_al = base & ~3;
+    const uint32_t base_sh = (uint32_t)(base & 3);
+    uint32_t sel[4], coef[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sel[k] = (uint32_t)(tx[k].ofs - base) | 0x0C00u | ((uint32_t)(tx[k].ofs1 - base) << 16) | 0x0C000000u;
+        coef[k] = (uint32_t)(uint16_t)tx[k].c0 | ((uint32_t)(uint16_t)tx[k].c1 << 16);
+    }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int ly = (tid >> 6) + 4 * rr;
@@ -82,13 +102,31 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
         const uint8_t* r0 = s_src + ty.ofs;
         const uint8_t* r1 = s_src + ty.ofs1;
         uint32_t out = 0;
+        if (fits) {
+            // three aligned dwords per row, shifted into place (unaligned LDS reads are much slower)
+            const uint32_t* q0 = reinterpret_cast<const uint32_t*>(r0 + base_al);
+            const uint32_t* q1 = reinterpret_cast<const uint32_t*>(r1 + base_al);
+            const uint32_t a0 = q0[0], a1 = q0[1], a2 = q0[2], b0 = q1[0], b1 = q1[1], b2 = q1[2];
+            const uint32_t a_lo = __builtin_amdgcn_alignbyte(a1, a0, base_sh), a_hi = __builtin_amdgcn_alignbyte(a2, a1, base_sh);
+            const uint32_t b_lo = __builtin_amdgcn_alignbyte(b1, b0, base_sh), b_hi = __builtin_amdgcn_alignbyte(b2, b1, base_sh);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int t0 = (int)__umul24(r0[tx[k].ofs], tx[k].c0) + (int)__umul24(r0[tx[k].ofs1], tx[k].c1);
-            const int t1 = (int)__umul24(r1[tx[k].ofs], tx[k].c0) + (int)__umul24(r1[tx[k].ofs1], tx[k].c1);
-            int v = (((ty.c0 * (t0 >> 4)) >> 16) + ((ty.c1 * (t1 >> 4)) >> 16) + 2) >> 2;
-            v = min(max(v, 0), 255);
-            out |= (uint32_t)v << (8 * k);
+            for (int k = 0; k < 4; ++k) {
+                const int t0 = (int)udot2(__builtin_amdgcn_perm(a_hi, a_lo, sel[k]), coef[k], 0u);
+                const int t1 = (int)udot2(__builtin_amdgcn_perm(b_hi, b_lo, sel[k]), coef[k], 0u);
+                // both terms are below 2^24; the result is in [0, 255] (the weights of an axis sum to 2048)
+                const int v = (int)(__umul24((uint32_t)ty.c0, (uint32_t)(t0 >> 4)) >> 16) +
+                              (int)(__umul24((uint32_t)ty.c1, (uint32_t)(t1 >> 4)) >> 16);
+                out |= (uint32_t)((v + 2) >> 2) << (8 * k);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t0 = (int)__umul24(r0[tx[k].ofs], tx[k].c0) + (int)__umul24(r0[tx[k].ofs1], tx[k].c1);
+                const int t1 = (int)__umul24(r1[tx[k].ofs], tx[k].c0) + (int)__umul24(r1[tx[k].ofs1], tx[k].c1);
+                int v = (((ty.c0 * (t0 >> 4)) >> 16) + ((ty.c1 * (t1 >> 4)) >> 16) + 2) >> 2;
+                v = min(max(v, 0), 255);
+                out |= (uint32_t)v << (8 * k);
+            }
         }
         uint8_t* d = D + (uint64_t)(dy_first + ly) * dpitch;
         if (nvalid == 4) {
@@ -124,10 +162,6 @@ constexpr int kBlurRows = 32;
 constexpr int kBlurPF = 4;
 constexpr int kBlurEdgeRows = 128;  // output rows per edge block
 
-typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t taps, uint32_t c) {
-    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, taps), c, false);
-}
 // Column pass for one pixel at row r.  pr[j % 6] holds the row sums of rows (j, j+1) packed as
 // two u16; the window rows r-6 .. r are pr[(r-6)%6], pr[(r-4)%6], pr[(r-2)%6] and the fresh sum.
 __device__ __forceinline__ uint32_t blur_col(const uint32_t (&pr)[6][4], uint32_t w_r, int r, int k) {
