@@ -3,7 +3,7 @@
 // in device memory.  Three launches over all pairs of a batch:
 //   k_stereo_rows    buckets the right keypoints by the first image row of their row band
 //                    (the row table of :494-512, as a counting sort);
-//   k_stereo_search  one wave per left keypoint: Hamming search over the buckets that can
+//   k_stereo_search  eight lanes per left keypoint: Hamming search over the buckets that can
 //                    hold its row (:523-568), then the 11x11 sliding-window distance over
 //                    11 shifts and the parabola fit (:570-642);
 //   k_stereo_cut     median of the accepted window distances and the 1.5*1.4*median cut
@@ -45,6 +45,7 @@ struct StereoDev {
     int32_t rows;                    // level-0 image rows (:492)
     float max_d;                     // mbf / mb (:517)
     float mbf;
+    int32_t border_only;             // diagnostic: no window takes the dword loader
     // scratch and outputs, per pair
     uint32_t* row_start;             // [rows + 1] first bucket entry of each row, [rows] = count
     StereoMeta* meta;                // [kp_cap]
@@ -120,23 +121,28 @@ __global__ __launch_bounds__(256) void k_stereo_rows(StereoDev S) {
     }
 }
 
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d, 64));
-    return v;
-}
-
 __device__ __forceinline__ int stereo_px(const uint8_t* img, int pitch, int w, int h, int x, int y) {
     x = x < 0 ? -x : x;
     x = x >= w ? 2 * w - 2 - x : x;
     y = y < 0 ? -y : y;
     y = y >= h ? 2 * h - 2 - y : y;
+    x = min(max(x, 0), w - 1);  // only bytes the distance never reads can lie this far out
+    y = min(max(y, 0), h - 1);
     return img[(int64_t)y * pitch + x];
 }
 
+constexpr int kStereoWinL = 11 * 16;              // left window rows, pitch 16
+constexpr int kStereoWin = kStereoWinL + 11 * 32;  // + right strip rows, pitch 32
+
 // grid = (ceil(kp_cap / kStereoKpPerBlock), pairs), block = 256.
+// A wave works on eight left keypoints at once, eight lanes each (group = lane >> 3), so that the
+// dependent global loads of the eight (keypoint -> bucket bounds -> bucket entries -> descriptors ->
+// matched right keypoint -> windows) overlap instead of queueing behind one another.
 __global__ __launch_bounds__(256) void k_stereo_search(StereoDev S) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[4][8][kStereoWin];
+    __shared__ uint32_t s_acc[4][8][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = blockIdx.y;
+    const int grp = lane >> 3, j = lane & 7;
     const int n_l = min(S.n_l[(int64_t)p * S.n_step], S.kp_cap);
     const int first = blockIdx.x * kStereoKpPerBlock + wave * (kStereoKpPerBlock / 4);
     if (first >= n_l) return;
@@ -149,28 +155,34 @@ __global__ __launch_bounds__(256) void k_stereo_search(StereoDev S) {
     const int wmax = S.wmax[p];
     const int img_l = S.first_l + p * S.step, img_r = S.first_r + p * S.step;
 
-    for (int q = 0; q < kStereoKpPerBlock / 4; ++q) {
-        const int iL = first + q;
-        if (iL >= n_l) break;
-        float out_u = -1.0f, out_d = -1.0f;
-        int out_sad = -1;
-        const orbx_kp kl = kps_l[iL];  // same address in every lane
-        const int level = kl.octave;
-        const float uL = kl.x, vL = kl.y;
-        const int row = (int)vL;  // :530
-        const float minU = __fsub_rn(uL, S.max_d), maxU = uL;  // minD = 0
-        uint32_t key = 0xFFFFFFFFu;
-        if (row >= 0 && row < S.rows && !(maxU < 0)) {
-            const uint4* dl = reinterpret_cast<const uint4*>(desc_l + (int64_t)iL * 32);
-            const uint4 dl0 = dl[0], dl1 = dl[1];
-            const int lo = (int)row_start[max(0, row - wmax)], hi = (int)row_start[row + 1];
-            for (int k = lo + lane; k < hi; k += 64) {
-                const StereoMeta m = meta[k];
-                const int minr = (int)(int16_t)(m.rows & 0xFFFFu), maxr = (int)(int16_t)(m.rows >> 16);
-                const int oct = (int)(m.id >> 16), iR = (int)(m.id & 0xFFFFu);
-                if (row < minr || row > maxr) continue;
-                if (oct < level - 1 || oct > level + 1) continue;  // :552
-                if (!(m.x >= minU && m.x <= maxU)) continue;       // :557
+    const int iL = first + grp;
+    const bool have = iL < n_l;
+    const orbx_kp kl = kps_l[have ? iL : first];
+    const int level = kl.octave;
+    const float uL = kl.x, vL = kl.y;
+    const int row = (int)vL;  // :530
+    const float minU = __fsub_rn(uL, S.max_d), maxU = uL;  // minD = 0
+
+    // ---- Hamming search over the buckets that can hold this row (:523-568)
+    uint32_t key = 0xFFFFFFFFu;
+    {
+        int k = 0, hi = 0;
+        if (have && row >= 0 && row < S.rows && !(maxU < 0)) {
+            k = (int)row_start[max(0, row - wmax)] + j;
+            hi = (int)row_start[row + 1];
+        }
+        const uint4* dl = reinterpret_cast<const uint4*>(desc_l + (int64_t)(have ? iL : first) * 32);
+        const uint4 dl0 = dl[0], dl1 = dl[1];
+        StereoMeta m = {0.0f, 0u, 0u};
+        if (k < hi) m = meta[k];
+        while (k < hi) {
+            const int kn = k + 8;
+            StereoMeta mn = m;
+            if (kn < hi) mn = meta[kn];  // in flight while this entry's descriptor is fetched
+            const int minr = (int)(int16_t)(m.rows & 0xFFFFu), maxr = (int)(int16_t)(m.rows >> 16);
+            const int oct = (int)(m.id >> 16), iR = (int)(m.id & 0xFFFFu);
+            if (row >= minr && row <= maxr && oct >= level - 1 && oct <= level + 1 &&  // :552
+                m.x >= minU && m.x <= maxU) {                                          // :557
                 const uint4* dr = reinterpret_cast<const uint4*>(desc_r + (int64_t)iR * 32);
                 const uint4 r0 = dr[0], r1 = dr[1];
                 const int dist = __popc(dl0.x ^ r0.x) + __popc(dl0.y ^ r0.y) + __popc(dl0.z ^ r0.z) + __popc(dl0.w ^ r0.w) +
@@ -178,99 +190,151 @@ __global__ __launch_bounds__(256) void k_stereo_search(StereoDev S) {
                 // first strict minimum in index order (:562) == minimum of (distance, index)
                 if (dist < 100) key = min(key, ((uint32_t)dist << 16) | (uint32_t)iR);  // TH_HIGH
             }
+            m = mn;
+            k = kn;
         }
-        key = wave_min_u32(key);
-        const int best_dist = (int)(key >> 16);
-        if (key != 0xFFFFFFFFu && best_dist < 75) {  // thOrbDist = (TH_HIGH + TH_LOW) / 2, :571
-            const int best_r = (int)(key & 0xFFFFu);
-            const float uR0 = kps_r[best_r].x;
-            const float sf = S.inv_scale[level];
-            const float scaled_ul = roundf(__fmul_rn(kl.x, sf));
-            const float scaled_vl = roundf(__fmul_rn(kl.y, sf));
-            const float scaled_ur0 = roundf(__fmul_rn(uR0, sf));
-            const int lw = S.w[level], lh = S.h[level];
-            // iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1 with L = w = 5 (:592-595)
-            if (!(scaled_ur0 < 0 || __fadd_rn(scaled_ur0, 11.0f) >= (float)lw)) {
-                const uint8_t* IL = S.img_l[level] + (uint64_t)img_l * S.plane_l[level];
-                const uint8_t* IR = S.img_r[level] + (uint64_t)img_r * S.plane_r[level];
-                const int pl = S.pitch_l[level], pr = S.pitch_r[level];
-                const int xl = (int)scaled_ul - 5, yl = (int)scaled_vl - 5;
-                // lane = g * 11 + s: shift s (incR = s - 5), rows g, g + 5, g + 10 of the window
-                const int s = lane % 11, g = lane / 11;
-                const int xr = (int)scaled_ur0 - 5 + (s - 5);
-                uint32_t acc = 0;
-                if (lane < 55) {
-                    const bool inside = xl >= 0 && xl + 12 <= lw && xr >= 0 && xr + 12 <= lw && yl >= 0 && yl + 11 <= lh;
-                    if (inside) {
-                        const int cl = IL[(int64_t)(yl + 5) * pl + xl + 5], cr = IR[(int64_t)(yl + 5) * pr + xr + 5];
-                        const int dc = cl - cr;
-                        for (int r = g; r < 11; r += 5) {
-                            const uint8_t* rl = IL + (int64_t)(yl + r) * pl + xl;
-                            const uint8_t* rr = IR + (int64_t)(yl + r) * pr + xr;
-                            uint32_t a[3], b[3];
 #pragma unroll
-                            for (int d = 0; d < 3; ++d) {
-                                a[d] = *reinterpret_cast<const u32_unaligned*>(rl + 4 * d);
-                                b[d] = *reinterpret_cast<const u32_unaligned*>(rr + 4 * d);
-                            }
+        for (int d = 4; d >= 1; d >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, d, 64));
+    }
+
+    // ---- the group stages its two windows in LDS (:570-600)
+    float scaled_ur0 = 0.0f;
+    bool refine = false;
+    uint8_t* wl = s_win[wave][grp];
+    uint8_t* wr = wl + kStereoWinL;
+    if (key != 0xFFFFFFFFu && (int)(key >> 16) < 75) {  // thOrbDist = (TH_HIGH + TH_LOW) / 2, :571
+        const int best_r = (int)(key & 0xFFFFu);
+        const float uR0 = kps_r[best_r].x;
+        const float sf = S.inv_scale[level];
+        const float scaled_ul = roundf(__fmul_rn(kl.x, sf));
+        const float scaled_vl = roundf(__fmul_rn(kl.y, sf));
+        scaled_ur0 = roundf(__fmul_rn(uR0, sf));
+        const int lw = S.w[level], lh = S.h[level];
+        // iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1 with L = w = 5 (:592-595)
+        if (!(scaled_ur0 < 0 || __fadd_rn(scaled_ur0, 11.0f) >= (float)lw)) {
+            refine = true;
+            const uint8_t* IL = S.img_l[level] + (uint64_t)img_l * S.plane_l[level];
+            const uint8_t* IR = S.img_r[level] + (uint64_t)img_r * S.plane_r[level];
+            const int pl = S.pitch_l[level], pr = S.pitch_r[level];
+            const int xl = (int)scaled_ul - 5, yl = (int)scaled_vl - 5;
+            const int xr0 = (int)scaled_ur0 - 10;  // left end of the window of shift incR = -5
+            // 11 rows of 12 (left) and 24 (right, all 11 shifts) bytes, fetched as dwords
+            if (!S.border_only && xl >= 0 && xl + 12 <= lw && xr0 >= 0 && xr0 + 24 <= lw && yl >= 0 && yl + 11 <= lh) {
+                // lanes 0-2: the left row's dwords; lanes 3-7: right dwords 0-4; right dword 5 of
+                // rows j and j + 8 afterwards
+                const bool is_l = j < 3;
+                const int pitch = is_l ? pl : pr;
+                const uint8_t* src = is_l ? IL + (int64_t)yl * pl + xl + 4 * j : IR + (int64_t)yl * pr + xr0 + 4 * (j - 3);
+                uint8_t* dst = is_l ? wl + 4 * j : wr + 4 * (j - 3);
+                const int dpitch = is_l ? 16 : 32;
+                uint32_t v[11];
 #pragma unroll
-                            for (int xx = 0; xx < 11; ++xx) {
-                                const int pa = (int)((a[xx >> 2] >> (8 * (xx & 3))) & 0xFFu);
-                                const int pb = (int)((b[xx >> 2] >> (8 * (xx & 3))) & 0xFFu);
-                                // |(pa - cl) - (pb - cr)|; v_sad_u32 would do it in one instruction but issues
-                                // at a quarter of the rate of sub/max
-                                const int t = pa - pb - dc;
-                                acc += (uint32_t)max(t, -t);
-                            }
-                        }
+                for (int r = 0; r < 11; ++r) v[r] = *reinterpret_cast<const u32_unaligned*>(src + (int64_t)r * pitch);
+                const uint8_t* src5 = IR + (int64_t)(yl + j) * pr + xr0 + 20;
+                const uint32_t e0 = *reinterpret_cast<const u32_unaligned*>(src5);
+                uint32_t e1 = 0;
+                if (j < 3) e1 = *reinterpret_cast<const u32_unaligned*>(src5 + (int64_t)8 * pr);
+#pragma unroll
+                for (int r = 0; r < 11; ++r) *reinterpret_cast<uint32_t*>(dst + r * dpitch) = v[r];
+                *reinterpret_cast<uint32_t*>(wr + j * 32 + 20) = e0;
+                if (j < 3) *reinterpret_cast<uint32_t*>(wr + (j + 8) * 32 + 20) = e1;
+            } else {
+                // windows reaching into the pyramid border: reflect-101 continuation (:1239-1245)
+                for (int i = j; i < 11 * 12 + 11 * 24; i += 8) {
+                    if (i < 11 * 12) {
+                        const int r = i / 12, c = i - 12 * r;
+                        wl[r * 16 + c] = (uint8_t)stereo_px(IL, pl, lw, lh, xl + c, yl + r);
                     } else {
-                        // windows reaching into the pyramid border: reflect-101 continuation (:1239-1245)
-                        const int cl = stereo_px(IL, pl, lw, lh, xl + 5, yl + 5), cr = stereo_px(IR, pr, lw, lh, xr + 5, yl + 5);
-                        for (int r = g; r < 11; r += 5)
-                            for (int xx = 0; xx < 11; ++xx) {
-                                const int da = stereo_px(IL, pl, lw, lh, xl + xx, yl + r) - cl;
-                                const int db = stereo_px(IR, pr, lw, lh, xr + xx, yl + r) - cr;
-                                acc += (uint32_t)abs(da - db);
-                            }
-                    }
-                }
-                // sum the five row groups of each shift into lanes 0..10
-                uint32_t tot = acc;
-#pragma unroll
-                for (int gg = 1; gg < 5; ++gg) tot += (uint32_t)__shfl((int)acc, (lane + 11 * gg) & 63, 64);
-                // first strict minimum over incR = -5..5 (:604) == minimum of (distance, shift)
-                const uint32_t k2 = wave_min_u32(lane < 11 ? (tot << 8) | (uint32_t)lane : 0xFFFFFFFFu);
-                const int sb = (int)(k2 & 0xFFu);
-                const int best_w = (int)(k2 >> 8);
-                const float d1 = (float)(uint32_t)__shfl((int)tot, (sb + 63) & 63, 64);
-                const float d2 = (float)(uint32_t)__shfl((int)tot, sb, 64);
-                const float d3 = (float)(uint32_t)__shfl((int)tot, (sb + 1) & 63, 64);
-                if (sb != 0 && sb != 10) {  // :613
-                    // :621, float arithmetic in the reference's order
-                    const float den = __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2)));
-                    const float delta = __fdiv_rn(__fsub_rn(d1, d3), den);
-                    if (!(delta < -1 || delta > 1)) {
-                        float best_ur = __fmul_rn(S.scale[level], __fadd_rn(__fadd_rn(scaled_ur0, (float)(sb - 5)), delta));  // :627
-                        float disparity = __fsub_rn(uL, best_ur);
-                        if (disparity >= 0 && disparity < S.max_d) {  // :631
-                            if (disparity <= 0) {  // :633-637 (double constants)
-                                disparity = (float)0.01;
-                                best_ur = (float)((double)uL - 0.01);
-                            }
-                            out_d = __fdiv_rn(S.mbf, disparity);
-                            out_u = best_ur;
-                            out_sad = best_w;
-                        }
+                        const int t = i - 11 * 12, r = t / 24, c = t - 24 * r;
+                        wr[r * 32 + c] = (uint8_t)stereo_px(IR, pr, lw, lh, xr0 + c, yl + r);
                     }
                 }
             }
         }
-        if (lane == 0) {
-            const size_t o = (size_t)p * S.kp_cap + iL;
-            S.u_right[o] = out_u;
-            S.depth[o] = out_d;
-            S.sad[o] = out_sad;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- window distances, one keypoint after the other with 55 lanes: lane = g * 11 + s is
+    // shift s (incR = s - 5) over rows g, g + 5, g + 10 (:597-611)
+    const uint64_t todo = __ballot(refine);
+    {
+        const int s = lane % 11, g = lane / 11;
+        const int q4 = s & ~3;
+        const uint32_t sh = (uint32_t)(s & 3);
+        for (int q = 0; q < 8; ++q) {
+            if (!((todo >> (8 * q)) & 1)) continue;  // wave-uniform
+            const uint8_t* ql = s_win[wave][q];
+            const uint8_t* qr = ql + kStereoWinL;
+            if (lane < 55) {
+                const int dc = (int)ql[5 * 16 + 5] - (int)qr[5 * 32 + s + 5];
+                uint32_t acc = 0;
+                for (int r = g; r < 11; r += 5) {
+                    const uint4 av = *reinterpret_cast<const uint4*>(ql + r * 16);
+                    const uint32_t* rq = reinterpret_cast<const uint32_t*>(qr + r * 32 + q4);
+                    const uint32_t r0 = rq[0], r1 = rq[1], r2 = rq[2], r3 = rq[3];
+                    const uint32_t a[3] = {av.x, av.y, av.z};
+                    const uint32_t b[3] = {__builtin_amdgcn_alignbyte(r1, r0, sh), __builtin_amdgcn_alignbyte(r2, r1, sh),
+                                           __builtin_amdgcn_alignbyte(r3, r2, sh)};
+#pragma unroll
+                    for (int xx = 0; xx < 11; ++xx) {
+                        const int pa = (int)((a[xx >> 2] >> (8 * (xx & 3))) & 0xFFu);
+                        const int pb = (int)((b[xx >> 2] >> (8 * (xx & 3))) & 0xFFu);
+                        // |(pa - cl) - (pb - cr)|; v_sad_u32 would do it in one instruction but issues
+                        // at a quarter of the rate of sub/max
+                        const int t = pa - pb - dc;
+                        acc += (uint32_t)max(t, -t);
+                    }
+                }
+                s_acc[wave][q][lane] = acc;
+            }
         }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- best shift and the parabola through its neighbours, per group (:604-642)
+    float out_u = -1.0f, out_d = -1.0f;
+    int out_sad = -1;
+    if (refine) {
+        uint32_t* qa = s_acc[wave][grp];
+        const uint32_t t0 = qa[j] + qa[11 + j] + qa[22 + j] + qa[33 + j] + qa[44 + j];  // shift j
+        uint32_t t1 = 0;                                                               // shift 8 + j
+        if (j < 3) t1 = qa[8 + j] + qa[19 + j] + qa[30 + j] + qa[41 + j] + qa[52 + j];
+        // first strict minimum over incR = -5..5 (:604) == minimum of (distance, shift)
+        uint32_t k2 = (t0 << 8) | (uint32_t)j;
+        if (j < 3) k2 = min(k2, (t1 << 8) | (uint32_t)(8 + j));
+        __builtin_amdgcn_wave_barrier();  // every partial sum was read
+        qa[j] = t0;
+        if (j < 3) qa[8 + j] = t1;
+#pragma unroll
+        for (int d = 4; d >= 1; d >>= 1) k2 = min(k2, (uint32_t)__shfl_xor((int)k2, d, 64));
+        __builtin_amdgcn_wave_barrier();
+        const int sb = (int)(k2 & 0xFFu);
+        const int best_w = (int)(k2 >> 8);
+        if (sb != 0 && sb != 10) {  // :613
+            const float d1 = (float)qa[sb - 1], d2 = (float)qa[sb], d3 = (float)qa[sb + 1];
+            // :621, float arithmetic in the reference's order
+            const float den = __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2)));
+            const float delta = __fdiv_rn(__fsub_rn(d1, d3), den);
+            if (!(delta < -1 || delta > 1)) {
+                float best_ur = __fmul_rn(S.scale[level], __fadd_rn(__fadd_rn(scaled_ur0, (float)(sb - 5)), delta));  // :627
+                float disparity = __fsub_rn(uL, best_ur);
+                if (disparity >= 0 && disparity < S.max_d) {  // :631
+                    if (disparity <= 0) {  // :633-637 (double constants)
+                        disparity = (float)0.01;
+                        best_ur = (float)((double)uL - 0.01);
+                    }
+                    out_d = __fdiv_rn(S.mbf, disparity);
+                    out_u = best_ur;
+                    out_sad = best_w;
+                }
+            }
+        }
+    }
+    if (have && j == 0) {
+        const size_t o = (size_t)p * S.kp_cap + iL;
+        S.u_right[o] = out_u;
+        S.depth[o] = out_d;
+        S.sad[o] = out_sad;
     }
 }
 

@@ -554,6 +554,8 @@ int run_stereo(orbx_ctx* l, orbx_ctx* r, int n_pairs, int first_l, int first_r, 
     S.rows = BL.lv[0].h;
     S.max_d = mbf / mb;  // :517, float division
     S.mbf = mbf;
+    // diagnostic: ORBX_STEREO_BORDER_PATH=1 loads every window through the reflecting byte loader
+    S.border_only = std::getenv("ORBX_STEREO_BORDER_PATH") != nullptr;
     int rc;
     if ((rc = ensure(l, &l->d_st_rows, (size_t)n_pairs * (S.rows + 1) * 4))) return rc;
     if ((rc = ensure(l, &l->d_st_meta, (size_t)n_pairs * kp_cap * sizeof(StereoMeta)))) return rc;

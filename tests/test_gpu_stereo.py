@@ -51,6 +51,13 @@ def test_stereo_two_contexts(oracle, w, h, nf, nl, disp):
     exr.close()
 
 
+def test_stereo_border_loader(oracle, monkeypatch):
+    """Windows that reach into a level's border are loaded byte by byte with reflection; the
+    diagnostic switch sends every window that way, and the results must not change."""
+    monkeypatch.setenv("ORBX_STEREO_BORDER_PATH", "1")
+    test_stereo_two_contexts(oracle, 752, 480, 1200, 8, 5)
+
+
 def test_stereo_batch_device(oracle):
     from hip_rt import DeviceArray
     w, h, nf, nl = 752, 480, 1200, 8
