@@ -137,6 +137,113 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     }
 }
 
+// Streaming form of the same resize, used when every run of four destination columns reads at
+// most eight consecutive source bytes (any scale factor up to 2) and the row taps never move
+// backwards.  No LDS: a lane owns four adjacent destination columns of one frame and walks down
+// a band of destination rows.  Per SOURCE row it loads its eight bytes once (one unaligned
+// 8-byte buffer load, kRsPF rows ahead of their use), forms the four horizontal sums
+// (v_perm_b32 + v_dot2_u32_u16 with the weights pre-multiplied by 16, masked to the value
+// (T >> 4) << 8), and keeps them for the next source row; a destination row is emitted when its
+// second source row has been formed, so a source row shared by two destination rows is
+// filtered once.  (b * (T >> 4)) >> 16 is one v_mul_hi_u32_u24 of (b << 8) and ((T >> 4) << 8).
+// The lanes of a row band are dealt over (frame, dword column) pairs in one sequence, so waves
+// are full whatever the level width; all lanes of a workgroup share the band and with it the
+// source-row schedule, which keeps the control flow scalar.
+// grid = (ceil(frames * ceil(dw/4) / 256), ceil(dh / rows_per_item)), block = 256.
+constexpr int kRsPF = 4;  // source rows in flight per lane
+
+__device__ __forceinline__ uint32_t mul_hi_u24(uint32_t a, uint32_t b) {  // both below 2^24
+    uint32_t r;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// Row tap y as two scalars: x = ofs | ofs1 << 16, y = c0 | c1 << 16.  The index is wave-uniform;
+// loading the entry as one 8-byte word lets the compiler use a scalar load.
+__device__ __forceinline__ uint2 resize_row_tap(const ResizeTap* __restrict__ yt, int y) {
+    const uint2 t = reinterpret_cast<const uint2*>(yt)[y];
+    return make_uint2(__builtin_amdgcn_readfirstlane(t.x), __builtin_amdgcn_readfirstlane(t.y));
+}
+
+__global__ __launch_bounds__(256) void k_resize_rows(const uint8_t* __restrict__ src, int spitch, uint64_t splane,
+                                                     uint8_t* __restrict__ dst, int dpitch, uint64_t dplane, int dw, int dh,
+                                                     const ResizeTap* __restrict__ xt, const ResizeTap* __restrict__ yt,
+                                                     int n_frames, int rows_per_item) {
+    const int nd = (dw + 3) >> 2;
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    const bool live = item < n_frames * nd;
+    const int f = live ? item / nd : 0;
+    const int x0 = live ? 4 * (item - f * nd) : 0;
+    const int nvalid = min(4, dw - x0);
+    ResizeTap tx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tx[k] = xt[min(x0 + k, dw - 1)];
+    // the eight bytes start at the first tap, or earlier when that would run over the row's end
+    const int base = min((int)tx[0].ofs, spitch - 8);
+    uint32_t sel[4], coef[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sel[k] = (uint32_t)(tx[k].ofs - base) | 0x0C00u | ((uint32_t)(tx[k].ofs1 - base) << 16) | 0x0C000000u;
+        coef[k] = ((uint32_t)(uint16_t)tx[k].c0 << 4) | ((uint32_t)(uint16_t)tx[k].c1 << 20);
+    }
+    const int kOut = 0x7FFFFFF0;  // beyond the buffer: the hardware drops the access
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, (int)(splane * (uint64_t)n_frames), 0x00020000);
+    const int vsrc = live ? (int)((uint64_t)f * splane) + base : kOut;
+    uint8_t* D = dst + (uint64_t)f * dplane + x0;
+
+    const int y0 = blockIdx.y * rows_per_item, y_end = min(y0 + rows_per_item, dh);
+    // taps of the next two destination rows, fetched ahead of their use
+    uint2 t_cur = resize_row_tap(yt, y0), t_nxt = resize_row_tap(yt, min(y0 + 1, dh - 1));
+    const int s0 = (int)(t_cur.x & 0xFFFFu);
+    const int s_last = (int)(resize_row_tap(yt, y_end - 1).x >> 16);
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 q[kRsPF];
+#pragma unroll
+    for (int k = 0; k < kRsPF; ++k) q[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, vsrc, min(s0 + k, s_last) * spitch, 0);
+    uint32_t Xp[4] = {0, 0, 0, 0};
+    int y = y0;
+    for (int sb = s0; sb <= s_last; sb += kRsPF) {
+#pragma unroll
+        for (int k = 0; k < kRsPF; ++k) {
+            const int sr = sb + k;
+            if (sr > s_last) break;
+            const u32x2 v = q[k];
+            q[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, vsrc, min(sr + kRsPF, s_last) * spitch, 0);
+            uint32_t X[4];
+#pragma unroll
+            for (int px = 0; px < 4; ++px) X[px] = udot2(__builtin_amdgcn_perm(v.y, v.x, sel[px]), coef[px], 0u) & 0x00FFFF00u;
+            while (y < y_end && (int)(t_cur.x >> 16) == sr) {
+                if ((int)(t_cur.x & 0xFFFFu) == sr) {  // both taps on one row (the clamped last rows)
+#pragma unroll
+                    for (int px = 0; px < 4; ++px) Xp[px] = X[px];
+                }
+                const uint32_t b0 = (t_cur.y & 0xFFFFu) << 8, b1 = (t_cur.y >> 16) << 8;
+                uint32_t out = 0;
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    // both products are below 2^24 >> 8; the sum is in [0, 1020 + 2]
+                    const uint32_t t = mul_hi_u24(b0, Xp[px]) + mul_hi_u24(b1, X[px]) + 2u;
+                    out |= (t >> 2) << (8 * px);
+                }
+                if (live) {
+                    uint8_t* d = D + (uint64_t)y * dpitch;
+                    if (nvalid == 4) {
+                        *reinterpret_cast<uint32_t*>(d) = out;
+                    } else {
+                        for (int px = 0; px < nvalid; ++px) d[px] = (uint8_t)(out >> (8 * px));
+                    }
+                }
+                ++y;
+                t_cur = t_nxt;
+                t_nxt = resize_row_tap(yt, min(y + 1, dh - 1));
+            }
+#pragma unroll
+            for (int px = 0; px < 4; ++px) Xp[px] = X[px];
+        }
+    }
+}
+
 __device__ __forceinline__ int reflect101(int p, int len) {
     p = p < 0 ? -p : p;
     return p >= len ? 2 * len - 2 - p : p;

@@ -54,6 +54,7 @@ struct orbx_ctx {
     std::vector<CellDesc> cells;
     std::vector<TileDesc> tiles;
     int rs_pitch[ORBX_MAX_LEVELS], rs_rows[ORBX_MAX_LEVELS];  // resize source tile in LDS
+    bool rs_stream[ORBX_MAX_LEVELS];                          // level built by k_resize_rows
     int fast_tile_bytes = 0, fast_plane_bytes = 0, fast_queue_bytes = 0;
     size_t fast_lds = 0;
     int pitch[ORBX_MAX_LEVELS];
@@ -233,6 +234,20 @@ int set_geometry(orbx_ctx* c, int w, int h) {
             c->rs_rows[l] = span_r;
             const size_t need = (size_t)c->rs_pitch[l] * span_r + (kRsTW + kRsTH) * sizeof(ResizeTap);
             if (need > 60 * 1024 || (size_t)c->rs_pitch[l] * span_r > 32767) return ORBX_E_GEOMETRY;  // scale factor too large
+        }
+        {
+            // the streaming kernel needs the taps of four adjacent columns within eight source bytes
+            // and row taps that step forward by whole rows
+            bool ok = true;
+            for (size_t d0 = 0; d0 < xt.size() && ok; d0 += 4) {
+                const size_t d1 = std::min(xt.size(), d0 + 4) - 1;
+                for (size_t d = d0; d <= d1; ++d) ok = ok && xt[d].ofs >= xt[d0].ofs && xt[d].ofs1 >= xt[d0].ofs && xt[d].ofs1 - xt[d0].ofs <= 7;
+            }
+            for (size_t d = 0; d < yt.size() && ok; ++d) {
+                ok = ok && (yt[d].ofs1 == yt[d].ofs || yt[d].ofs1 == yt[d].ofs + 1);
+                if (d) ok = ok && yt[d].ofs >= yt[d - 1].ofs && yt[d].ofs1 >= yt[d - 1].ofs1;
+            }
+            c->rs_stream[l] = ok;
         }
         rc = ensure(c, &c->d_xt[l], xt.size() * sizeof(ResizeTap));
         if (rc) return rc;
@@ -440,6 +455,21 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     for (int l = 1; l < L; ++l) {
         const LevelDev& S = B.lv[l - 1];
         const LevelDev& D = B.lv[l];
+        // ORBX_RESIZE_TILES=1 (diagnostic) keeps the LDS-tiled kernel for every level
+        if (c->rs_stream[l] && std::getenv("ORBX_RESIZE_TILES") == nullptr && S.pitch >= 8 &&
+            (uint64_t)n * S.plane < 0x7FFFFFF0ull) {
+            const int nd = (D.w + 3) / 4;
+            // destination rows per lane: long bands filter fewer source rows twice, short ones give
+            // the small levels enough waves to hide their load latency
+            const unsigned blocks_x = ((unsigned)n * nd + 255) / 256;
+            int rows = 32;
+            while (rows > 8 && (uint64_t)blocks_x * 4 * ((D.h + rows - 1) / rows) < 16384) rows >>= 1;
+            dim3 grid_rows(blocks_x, (D.h + rows - 1) / rows);
+            hipLaunchKernelGGL(k_resize_rows, grid_rows, dim3(256), 0, aux, S.img, S.pitch, S.plane, const_cast<uint8_t*>(D.img),
+                               D.pitch, D.plane, D.w, D.h, (const ResizeTap*)c->d_xt[l].p, (const ResizeTap*)c->d_yt[l].p, n,
+                               rows);
+            continue;
+        }
         dim3 grid((D.w + kRsTW - 1) / kRsTW, (D.h + kRsTH - 1) / kRsTH, n);
         const size_t lds = (size_t)c->rs_pitch[l] * c->rs_rows[l] + (kRsTW + kRsTH) * sizeof(ResizeTap);
         hipLaunchKernelGGL(k_resize, grid, dim3(256), lds, aux, S.img, S.pitch, S.plane, S.w, S.h,

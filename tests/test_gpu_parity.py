@@ -271,6 +271,21 @@ def test_parameter_space(oracle, w, h, nf, scale, nl, ini, mn, cid):
     ex.close()
 
 
+def test_resize_tiled_kernel(oracle, monkeypatch):
+    """The pyramid has two resize kernels: the streaming one (taps of four columns within eight source
+    bytes) and the LDS-tiled one for everything else.  The diagnostic switch forces the tiled one."""
+    monkeypatch.setenv("ORBX_RESIZE_TILES", "1")
+    w, h = 752, 480
+    img = synth.make_frame(w, h, 4, 3)
+    ex = oa.ORBextractor(1200, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    orc = oracle.Oracle(1200, 1.2, 8, 20, 7)
+    kps, desc = ex(img)
+    okps, odesc = orc.extract(img)
+    _check_stages(ex, orc, img)
+    _check_final(kps, desc, okps, odesc)
+    ex.close()
+
+
 def test_device_input_unaligned(oracle):
     """Device-resident input whose pointer, stride and frame stride are not multiples of 4: the library
     cannot use it in place and copies it into its arena first."""
