@@ -54,6 +54,29 @@ __device__ __forceinline__ int arc_max(const int x[16]) {
     return best;
 }
 
+// The same on pairs of ring positions packed as two 16-bit lanes: X[j] holds (x[2j], x[2j+1]).
+// Only the first window step needs a lane shift (v_alignbit); the others combine whole pairs.
+typedef short fast_i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(fast_i16x2, a), __builtin_bit_cast(fast_i16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(fast_i16x2, a), __builtin_bit_cast(fast_i16x2, b)));
+}
+__device__ __forceinline__ int arc_max_pk(const uint32_t X[8]) {
+    uint32_t m2[8], m4[8], m8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m2[j] = pk_min_i16(X[j], __builtin_amdgcn_alignbit(X[(j + 1) & 7], X[j], 16));  // (x[2j+1], x[2j+2])
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m4[j] = pk_min_i16(m2[j], m2[(j + 1) & 7]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m8[j] = pk_min_i16(m4[j], m4[(j + 2) & 7]);
+    uint32_t best = pk_min_i16(m8[0], X[4]);
+#pragma unroll
+    for (int j = 1; j < 8; ++j) best = pk_max_i16(best, pk_min_i16(m8[j], X[(j + 4) & 7]));
+    return max((int)(short)(best & 0xFFFFu), (int)(short)(best >> 16));
+}
+
 typedef unsigned short fast_u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(fast_u16x2, a), __builtin_bit_cast(fast_u16x2, b)));
@@ -118,28 +141,24 @@ __device__ __forceinline__ void fast_score_range(const uint8_t* s_tile, uint8_t*
         const int e = s_queue[q], u = e & 0xFF, vq = e >> 8;
         if (u >= wd) continue;  // padding pixels of the last dword of a row
         const uint8_t* p = s_tile + (vq + 3) * TP + 4 + u;
-        const int cv = p[0];
-        int r[16];
-        r[0] = p[3 * TP];
-        r[1] = p[3 * TP + 1];
-        r[2] = p[2 * TP + 2];
-        r[3] = p[1 * TP + 3];
-        r[4] = p[3];
-        r[5] = p[-1 * TP + 3];
-        r[6] = p[-2 * TP + 2];
-        r[7] = p[-3 * TP + 1];
-        r[8] = p[-3 * TP];
-        r[9] = p[-3 * TP - 1];
-        r[10] = p[-2 * TP - 2];
-        r[11] = p[-1 * TP - 3];
-        r[12] = p[-3];
-        r[13] = p[1 * TP - 3];
-        r[14] = p[2 * TP - 2];
-        r[15] = p[3 * TP - 1];
-        int d[16];
+        const uint32_t cv2 = (uint32_t)p[0] * 0x00010001u;
+        // ring positions 2j and 2j+1 share a register
+        uint32_t P[8];
+        P[0] = (uint32_t)p[3 * TP] | ((uint32_t)p[3 * TP + 1] << 16);
+        P[1] = (uint32_t)p[2 * TP + 2] | ((uint32_t)p[1 * TP + 3] << 16);
+        P[2] = (uint32_t)p[3] | ((uint32_t)p[-1 * TP + 3] << 16);
+        P[3] = (uint32_t)p[-2 * TP + 2] | ((uint32_t)p[-3 * TP + 1] << 16);
+        P[4] = (uint32_t)p[-3 * TP] | ((uint32_t)p[-3 * TP - 1] << 16);
+        P[5] = (uint32_t)p[-2 * TP - 2] | ((uint32_t)p[-1 * TP - 3] << 16);
+        P[6] = (uint32_t)p[-3] | ((uint32_t)p[1 * TP - 3] << 16);
+        P[7] = (uint32_t)p[2 * TP - 2] | ((uint32_t)p[3 * TP - 1] << 16);
+        uint32_t D[8];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) d[k] = BRIGHT ? cv - r[k] : r[k] - cv;
-        const int S = arc_max(d);
+        for (int j = 0; j < 8; ++j) {
+            const fast_i16x2 a = __builtin_bit_cast(fast_i16x2, cv2), b = __builtin_bit_cast(fast_i16x2, P[j]);
+            D[j] = __builtin_bit_cast(uint32_t, BRIGHT ? a - b : b - a);
+        }
+        const int S = arc_max_pk(D);
         if (S > thr) {
             const int c = min((int)(((float)u + 0.5f) * inv_wcell), nc - 1);
             if (!RETRY || sh->th[c] >= 0) s_score[(vq + 1) * SP + 1 + u + c] = (uint8_t)(S - 1);
@@ -169,7 +188,6 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
     // Pixels whose ring is darker go to the front of the queue, brighter ones to its back, so that
     // step 2 runs each half of the score on a dense range.
     const int ndwd = (wd + 3) >> 2, n_items = hd * ndwd;
-    const uint32_t kM = 0x00FF00FFu, kBias = 0x01000100u;
     const uint32_t add_bright = (uint32_t)(0x8000 - 257 - thr) * 0x00010001u;
     const uint32_t sub_dark = (uint32_t)(0x8000 + 255 - thr) * 0x00010001u;
     // (row, dword) of item tid, advanced by 256 items per iteration without divisions
@@ -179,7 +197,7 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
     for (int i0 = 0; i0 < n_items; i0 += 256) {
         uint32_t pb[2] = {0, 0}, pd[2] = {0, 0};  // [0]: bits 15/31 = pixels 0/2, [1]: pixels 1/3
         if (v < hd) {
-            const uint8_t* pc = s_tile + (v + 3) * TP + 4 * j + 4;
+            const uint8_t* pc = s_tile + __umul24((uint32_t)(v + 3), (uint32_t)TP) + 4 * j + 4;
             const uint32_t Cd = *reinterpret_cast<const uint32_t*>(pc);
             const uint32_t Ud = *reinterpret_cast<const uint32_t*>(pc + 3 * TP);
             const uint32_t Dd = *reinterpret_cast<const uint32_t*>(pc - 3 * TP);
@@ -196,48 +214,67 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
             }
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {  // 0: pixels 0,2   1: pixels 1,3
-                const int sft = 8 * h2;
-                const uint32_t c = ((Cd >> sft) & kM) | kBias;
-                const uint32_t d0 = c - ((Ud >> sft) & kM), d8 = c - ((Dd >> sft) & kM);
-                const uint32_t d4 = c - ((Rd >> sft) & kM), d12 = c - ((Ld >> sft) & kM);
+                // one v_perm_b32 spreads two bytes over the 16-bit lanes; the centre takes its bias
+                // (high byte 1) from the second operand
+                const uint32_t sel_c = h2 ? 0x04030401u : 0x04020400u, sel_r = h2 ? 0x0C030C01u : 0x0C020C00u;
+                const uint32_t c = __builtin_amdgcn_perm(0x01010101u, Cd, sel_c);
+                const uint32_t d0 = c - __builtin_amdgcn_perm(0u, Ud, sel_r), d8 = c - __builtin_amdgcn_perm(0u, Dd, sel_r);
+                const uint32_t d4 = c - __builtin_amdgcn_perm(0u, Rd, sel_r), d12 = c - __builtin_amdgcn_perm(0u, Ld, sel_r);
                 const uint32_t br = pk_min_u16(pk_max_u16(d0, d8), pk_max_u16(d4, d12));
                 const uint32_t dk = pk_max_u16(pk_min_u16(d0, d8), pk_min_u16(d4, d12));
-                pb[h2] = (br + add_bright) & on[h2];
-                pd[h2] = (sub_dark - dk) & on[h2];
+                pb[h2] = br + add_bright;  // only bits 15 and 31 are read
+                pd[h2] = sub_dark - dk;
+                if (RETRY) {
+                    pb[h2] &= on[h2];
+                    pd[h2] &= on[h2];
+                }
             }
         }
         const int e0 = (v << 8) + 4 * j;
-        // masks of the passing pixels, [side][pixel of the dword]
+        // masks of the passing pixels, [side][pixel of the dword]: bit 15 of the even/odd word is the
+        // sign of its low half, bit 31 the sign of the word, so one compare gives each wave-wide mask
         uint64_t m[2][4];
-        bool hit[2][4];
         int tot[2];
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
             const uint32_t pe = side ? pd[0] : pb[0], po = side ? pd[1] : pb[1];
-            hit[side][0] = (pe & 0x8000u) != 0;
-            hit[side][1] = (po & 0x8000u) != 0;
-            hit[side][2] = (int)pe < 0;
-            hit[side][3] = (int)po < 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) m[side][b] = __ballot(hit[side][b]);
+            asm("v_cmp_gt_i16 %0, 0, %1" : "=s"(m[side][0]) : "v"(pe));
+            asm("v_cmp_gt_i16 %0, 0, %1" : "=s"(m[side][1]) : "v"(po));
+            asm("v_cmp_gt_i32 %0, 0, %1" : "=s"(m[side][2]) : "v"(pe));
+            asm("v_cmp_gt_i32 %0, 0, %1" : "=s"(m[side][3]) : "v"(po));
             tot[side] = __popcll(m[side][0]) + __popcll(m[side][1]) + __popcll(m[side][2]) + __popcll(m[side][3]);
         }
         if (tot[0] | tot[1]) {
-            // one counter update reserves both ends: front count in the low half, back count in the high half
+            // one counter update reserves both ends: front count in the low half, back count in the high
+            // half (issued as a plain LDS instruction: lane 0 alone adds for the wave)
             int base = 0;
-            if (lane == 0) base = atomicAdd(&sh->q_fb, tot[0] | (tot[1] << 16));
+            if (lane == 0) {
+                uint32_t got;
+                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                             : "=v"(got)
+                             : "v"((uint32_t)(uintptr_t)&sh->q_fb), "v"((uint32_t)(tot[0] | (tot[1] << 16)))
+                             : "memory");
+                base = (int)got;
+            }
             base = __builtin_amdgcn_readfirstlane(base);
+            const uint32_t eb[4] = {(uint32_t)e0, (uint32_t)e0 + 1u, (uint32_t)e0 + 2u, (uint32_t)e0 + 3u};
             // a reservation that does not fit is skipped as a whole; the overflow is detected after the loop
 #pragma unroll
             for (int side = 0; side < 2; ++side) {
                 int at = side ? (int)((uint32_t)base >> 16) : (base & 0xFFFF);
                 if (at + tot[side] > q_cap) continue;
+                // front: slots at, at+1, ... upwards from 0; back: q_cap-1-at, ... downwards.  The slot of a
+                // lane is the wave-uniform start plus (front) or minus (back) its rank among the hits.
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const uint64_t mm = m[side][b];
-                    if (hit[side][b]) {
-                        const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, (uint32_t)at));
-                        s_queue[side ? q_cap - 1 - r : r] = (uint16_t)(e0 + b);  // front grows up from 0, back down from q_cap - 1
+                    if (__builtin_amdgcn_inverse_ballot_w64(mm)) {
+                        const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+                        if (side) {
+                            (s_queue + (q_cap - 1 - at))[-r] = (uint16_t)eb[b];
+                        } else {
+                            (s_queue + at)[r] = (uint16_t)eb[b];
+                        }
                     }
                     at += __popcll(mm);
                 }
