@@ -195,9 +195,11 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
     int j = tid - v * ndwd;
     const int dv = 256 / ndwd, dj = 256 - dv * ndwd;
     for (int i0 = 0; i0 < n_items; i0 += 256) {
-        uint32_t pb[2] = {0, 0}, pd[2] = {0, 0};  // [0]: bits 15/31 = pixels 0/2, [1]: pixels 1/3
-        if (v < hd) {
-            const uint8_t* pc = s_tile + __umul24((uint32_t)(v + 3), (uint32_t)TP) + 4 * j + 4;
+        uint32_t pb[2], pd[2];  // [0]: bits 15/31 = pixels 0/2, [1]: pixels 1/3
+        // items past the end (last iteration only) test a row of the tile again; their hits are masked off
+        const uint64_t live = __ballot(v < hd);
+        {
+            const uint8_t* pc = s_tile + __umul24((uint32_t)(min(v, hd - 1) + 3), (uint32_t)TP) + 4 * j + 4;
             const uint32_t Cd = *reinterpret_cast<const uint32_t*>(pc);
             const uint32_t Ud = *reinterpret_cast<const uint32_t*>(pc + 3 * TP);
             const uint32_t Dd = *reinterpret_cast<const uint32_t*>(pc - 3 * TP);
@@ -232,18 +234,30 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
         }
         const int e0 = (v << 8) + 4 * j;
         // masks of the passing pixels, [side][pixel of the dword]: bit 15 of the even/odd word is the
-        // sign of its low half, bit 31 the sign of the word, so one compare gives each wave-wide mask
+        // sign of its low half, bit 31 the sign of the word, so one compare gives each wave-wide mask.
+        // The compares run with the lanes past the end switched off, which leaves their mask bits zero.
         uint64_t m[2][4];
+        {
+            uint64_t saved;
+            asm volatile(
+                "s_and_saveexec_b64 %[sv], %[live]\n\t"
+                "v_cmp_gt_i16 %[b0], 0, %[pbe]\n\t"
+                "v_cmp_gt_i16 %[b1], 0, %[pbo]\n\t"
+                "v_cmp_gt_i32 %[b2], 0, %[pbe]\n\t"
+                "v_cmp_gt_i32 %[b3], 0, %[pbo]\n\t"
+                "v_cmp_gt_i16 %[d0], 0, %[pde]\n\t"
+                "v_cmp_gt_i16 %[d1], 0, %[pdo]\n\t"
+                "v_cmp_gt_i32 %[d2], 0, %[pde]\n\t"
+                "v_cmp_gt_i32 %[d3], 0, %[pdo]\n\t"
+                "s_mov_b64 exec, %[sv]"
+                : [sv] "=&s"(saved), [b0] "=&s"(m[0][0]), [b1] "=&s"(m[0][1]), [b2] "=&s"(m[0][2]), [b3] "=&s"(m[0][3]),
+                  [d0] "=&s"(m[1][0]), [d1] "=&s"(m[1][1]), [d2] "=&s"(m[1][2]), [d3] "=&s"(m[1][3])
+                : [live] "s"(live), [pbe] "v"(pb[0]), [pbo] "v"(pb[1]), [pde] "v"(pd[0]), [pdo] "v"(pd[1]));
+        }
         int tot[2];
 #pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            const uint32_t pe = side ? pd[0] : pb[0], po = side ? pd[1] : pb[1];
-            asm("v_cmp_gt_i16 %0, 0, %1" : "=s"(m[side][0]) : "v"(pe));
-            asm("v_cmp_gt_i16 %0, 0, %1" : "=s"(m[side][1]) : "v"(po));
-            asm("v_cmp_gt_i32 %0, 0, %1" : "=s"(m[side][2]) : "v"(pe));
-            asm("v_cmp_gt_i32 %0, 0, %1" : "=s"(m[side][3]) : "v"(po));
+        for (int side = 0; side < 2; ++side)
             tot[side] = __popcll(m[side][0]) + __popcll(m[side][1]) + __popcll(m[side][2]) + __popcll(m[side][3]);
-        }
         if (tot[0] | tot[1]) {
             // one counter update reserves both ends: front count in the low half, back count in the high
             // half (issued as a plain LDS instruction: lane 0 alone adds for the wave)
