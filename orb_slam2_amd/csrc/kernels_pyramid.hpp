@@ -256,8 +256,9 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // Streaming form, all levels and frames in one launch: no LDS, register sliding window.
 // A level is cut into row tiles of kBlurRows rows; the (row tile, dword column) pairs of a level
 // are numbered linearly and dealt to lanes, so no lane idles at a strip end.  A lane owns four
-// adjacent columns of its row tile and walks down it: per source row it loads three aligned
-// dwords (pixels x0-4 .. x0+7, kBlurPF rows ahead of their use) through a buffer resource, forms
+// adjacent columns of its row tile and walks down it: per source row it loads its own dword
+// (kBlurPF rows ahead of its use, through a buffer resource), takes the dwords to its left and
+// right (pixels x0-4 .. x0-1 and x0+4 .. x0+7) from the neighbouring lanes, forms
 // the four row sums with v_alignbyte_b32 + v_dot4_u32_u8 (taps 18,34,49,55 | 49,34,18,0), keeps
 // the row sums of the last six rows packed in pairs and evaluates the column pass with
 // v_dot2_u32_u16, storing one dword per row.  Rows are reflected by index.  Dwords holding a
@@ -266,8 +267,9 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // those columns through a small LDS tile of row sums.
 // grid = (B.blur_first[nlevels], frames), block = 256.
 constexpr int kBlurRows = 32;
-constexpr int kBlurPF = 4;
+constexpr int kBlurPF = 8;
 constexpr int kBlurEdgeRows = 128;  // output rows per edge block
+constexpr int kBlurItems = 4 * 62;  // (row tile, dword column) pairs per streaming block: 62 per wave
 
 // Column pass for one pixel at row r.  pr[j % 6] holds the row sums of rows (j, j+1) packed as
 // two u16; the window rows r-6 .. r are pr[(r-6)%6], pr[(r-4)%6], pr[(r-2)%6] and the fresh sum.
@@ -287,7 +289,7 @@ __device__ __forceinline__ uint32_t gauss_tap(int j) {
 // Block counts of one level: streaming blocks, then edge blocks.
 __host__ __device__ inline int blur_main_blocks(int w, int h) {
     const int nd = (w + 3) >> 2, nty = (h + kBlurRows - 1) / kBlurRows;
-    return (nd * nty + 255) >> 8;
+    return (nd * nty + kBlurItems - 1) / kBlurItems;
 }
 __host__ __device__ inline int blur_edge_blocks(int h) { return (h + kBlurEdgeRows - 1) / kBlurEdgeRows; }
 
@@ -334,36 +336,41 @@ __global__ __launch_bounds__(256) void k_blur7_all(BatchDev B) {
         return;
     }
     const int nd = (w + 3) >> 2, nty = (h + kBlurRows - 1) / kBlurRows;
-    const int g = blk * 256 + tid;
-    const int ty = (int)(((float)g + 0.5f) * (1.0f / (float)nd));  // g / nd, exact for g < 2^22
+    // A wave covers 62 consecutive pairs with lanes 1..62; lanes 0 and 63 load the pairs before and
+    // after them and only serve as the left / right neighbour of lanes 1 and 62, so that every lane
+    // loads one dword per row and takes the two dwords beside it from the adjacent lanes
+    // (v_mov_b32_dpp wave_shr / wave_shl) instead of from memory.
+    const int lane = tid & 63;
+    const int g = blk * kBlurItems + (tid >> 6) * 62 + lane - 1;
+    const int ty = g < 0 ? nty : (int)(((float)g + 0.5f) * (1.0f / (float)nd));  // g / nd, exact for g < 2^22
     const int dcol = g - ty * nd;
     const bool live = ty < nty;
     const int x0 = dcol * 4;
     const int y0 = ty * kBlurRows;
-    // Buffer addressing: out-of-range accesses (column -4 of the first lane of row 0, idle lanes,
-    // lanes that own no full dword) are dropped by the hardware range check.
+    // Buffer addressing: out-of-range accesses (idle lanes, lanes that own no full dword) are
+    // dropped by the hardware range check.
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(S8), 0, h * spitch, 0x00020000);
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(D8, 0, h * dpitch, 0x00020000);
     const int kOut = 0x7FFFFFF0;
-    const bool store_ok = live && x0 >= 4 && x0 <= last_full;
-    const int vcol = live ? x0 - 4 : kOut;
-    uint32_t qL[kBlurPF], qC[kBlurPF], qR[kBlurPF];
+    // A lane whose neighbour lane holds another row tile (the first and last column of a tile) never
+    // stores: those columns belong to the edge blocks.
+    const bool store_ok = live && x0 >= 4 && x0 <= last_full && lane >= 1 && lane <= 62;
+    const int vcol = live ? x0 : kOut;
+    uint32_t qC[kBlurPF];
 #pragma unroll
     for (int r = 0; r < kBlurPF; ++r) {
         const int vo = reflect101(min(y0 + r - 3, h + 2), h) * spitch + vcol;
-        qL[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0, 0);
-        qC[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo + 4, 0, 0);
-        qR[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo + 8, 0, 0);
+        qC[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0, 0);
     }
     uint32_t pr[6][4], wp[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < kBlurRows + 6; ++r) {
-        const uint32_t Lw = qL[r % kBlurPF], C = qC[r % kBlurPF], R = qR[r % kBlurPF];
+        const uint32_t C = qC[r % kBlurPF];
+        const uint32_t Lw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x138, 0xF, 0xF, false);  // lane - 1
+        const uint32_t R = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x130, 0xF, 0xF, false);   // lane + 1
         if (r + kBlurPF < kBlurRows + 6) {
             const int vo = reflect101(min(y0 + r + kBlurPF - 3, h + 2), h) * spitch + vcol;
-            qL[r % kBlurPF] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0, 0);
-            qC[r % kBlurPF] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo + 4, 0, 0);
-            qR[r % kBlurPF] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo + 8, 0, 0);
+            qC[r % kBlurPF] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0, 0);
         }
         const uint32_t a0 = __builtin_amdgcn_alignbyte(C, Lw, 1), b0 = __builtin_amdgcn_alignbyte(R, C, 1);
         const uint32_t a1 = __builtin_amdgcn_alignbyte(C, Lw, 2), b1 = __builtin_amdgcn_alignbyte(R, C, 2);
