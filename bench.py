@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 # HBM bytes per launch from the committed rocprofv3 counter passes of this same command
 # (tools/traffic_pass.sh + tools/traffic_summary.py); counters cannot be read from inside the process.
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_traffic.json")
-STAGE_KERNEL = {"pyramid": "k_resize", "fast": "k_fast_tiles", "quadtree": "k_octree", "blur": "k_blur7_all",
+STAGE_KERNEL = {"pyramid": "k_resize_rows", "fast": "k_fast_tiles", "quadtree": "k_octree", "blur": "k_blur7_all",
                 "orient_describe": "k_orient_describe"}
 
 
@@ -41,6 +41,24 @@ def measured_traffic(stage, frames_per_step, launches):
         return t[STAGE_KERNEL[stage]]["traffic_bytes"] / launches * frames_per_step / 512.0
     except (OSError, KeyError, ValueError):
         return None
+
+
+VALU_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_valu.json")
+N_SIMD, VALU_CYCLES, CLOCK_HZ = 256 * 4, 4.0, 2.4e9  # a SIMD issues one wave64 vector instruction per 4 cycles
+
+
+def valu_view(stage, frames_per_step, serial_ms):
+    """The stage's kernel against the vector-issue ceiling: its counted wave instructions per step
+    (SQ_INSTS_VALU, profiles/) at one instruction per SIMD per 4 cycles, beside its measured time alone."""
+    try:
+        with open(VALU_FILE) as f:
+            t = json.load(f)
+        instr = t[STAGE_KERNEL[stage]]["SQ_INSTS_VALU"] * frames_per_step / 512.0
+    except (OSError, KeyError, ValueError):
+        return None
+    floor_ms = instr * VALU_CYCLES / N_SIMD / CLOCK_HZ * 1e3
+    return {"wave_instructions_per_step": instr, "issue_floor_ms": floor_ms, "serialised_ms": serial_ms,
+            "frac_of_issue_ceiling": floor_ms / serial_ms if serial_ms > 0 else None}
 
 
 def level_pixels(oa):
@@ -281,6 +299,7 @@ def main():
                         "(measured after the timed region)",
                 "serialised_ms_per_launch": serial_sum[dom] / (1 if dom == "fast" else launches[dom]),
                 "serialised_frac": stage_bytes[dom] * n / (serial_sum[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "valu_issue": valu_view(dom, n, serial_sum[dom]),
             },
             "path_roofline": {
                 "algorithmic_bytes_per_frame": b_frame,
