@@ -62,7 +62,7 @@ __device__ __forceinline__ void sincos_pinned(float angf, float* c_out, float* s
 
 constexpr int kPatchRows = 37, kPatchDw = 10, kPatchPitch = 40;  // blurred neighbourhood of a keypoint in LDS
 constexpr int kPatchLoads = (kPatchRows * kPatchDw + 63) / 64;      // dwords per lane
-constexpr int kDescPerWave = 8;              // keypoints a wave handles in turn
+constexpr int kDescPerWave = 4;              // keypoints a wave handles in turn
 constexpr int kDescKp = 4 * kDescPerWave;    // keypoints per workgroup
 
 // Wave-wide integer sum through DPP (no LDS traffic); the total lands in lane 63.
@@ -77,6 +77,19 @@ __device__ __forceinline__ int wave_sum_to_lane63(int v) {
 }
 
 typedef u32_unaligned desc_u32_unaligned;
+
+// Diagnostic build only (-DORBX_STAMPS_DESC): wave 0 adds the cycles between phase boundaries into
+// B.stamps[slot] (1024 copies spread by block id); the product build compiles these calls away.
+#ifdef ORBX_STAMPS_DESC
+#define ORBX_STAMP_D(B, slot, t0)                                                                  \
+    do {                                                                                           \
+        const unsigned long long t1_ = __builtin_amdgcn_s_memtime();                                \
+        if (threadIdx.x == 0 && (B).stamps) atomicAdd(&(B).stamps[(slot) + 16 * (blockIdx.x & 1023)], t1_ - (t0)); \
+        (t0) = __builtin_amdgcn_s_memtime();                                                        \
+    } while (0)
+#else
+#define ORBX_STAMP_D(B, slot, t0) do { (void)(t0); } while (0)
+#endif
 
 // One workgroup handles up to kDescKp retained keypoints of one (frame, level) in three phases:
 //  A. orientation moments: each wave takes its keypoints in turn; the 31x31 patch is read as 31
@@ -121,6 +134,10 @@ __global__ __launch_bounds__(256) void k_orient_describe(BatchDev B, const uint3
     int base_out = 0;
     for (int l = 0; l < level; ++l) base_out += counts[l];
     base_out += first;
+    unsigned long long t0 = 0;
+#ifdef ORBX_STAMPS_DESC
+    t0 = __builtin_amdgcn_s_memtime();
+#endif
     if (tid < nk) s_pk[tid] = lvl_kps[(uint64_t)frame * B.kp_total + L.kp_off + first + tid];
 
     // ---- lane constants of phase A: four patch dwords (row, dword-of-row) and their weights ----
@@ -161,35 +178,47 @@ __global__ __launch_bounds__(256) void k_orient_describe(BatchDev B, const uint3
         }
     }
     __syncthreads();
+    ORBX_STAMP_D(B, 0, t0);
 
     // ---- A. orientation moments (the next keypoint's patch is in flight while this one is reduced) ----
     const uint8_t* img = L.img + (uint64_t)frame * L.plane;
-    const int kp0 = wave * kDescPerWave;
-    const int cnt = max(0, min(kDescPerWave, nk - kp0));  // wave-uniform
+    // wave w takes keypoints w, w + 4, w + 8, ... of the workgroup's run, so a short run is shared evenly
+    const int cnt = max(0, (nk - wave + 3) >> 2);  // wave-uniform
     auto patch_ptr = [&](int kp) {
         const uint32_t pk = __builtin_amdgcn_readfirstlane(s_pk[kp]);
         return img + (uint64_t)(pt_y(pk) + kBorder) * L.pitch + (pt_x(pk) + kBorder);  // level coordinates (:936-937)
     };
-    uint4 nx = make_uint4(0, 0, 0, 0);
-    if (cnt > 0) nx = *reinterpret_cast<const uint4_unaligned*>(patch_ptr(kp0) + ic_off);
-    for (int q = 0; q < cnt; ++q) {
-        const uint32_t px[4] = {nx.x, nx.y, nx.z, nx.w};
-        if (q + 1 < cnt) nx = *reinterpret_cast<const uint4_unaligned*>(patch_ptr(kp0 + q + 1) + ic_off);
-        int su = 0, s1 = 0;
+    // eight patches are requested before the first one is reduced: the phase then costs one memory
+    // round trip per eight keypoints, not one per keypoint
+    constexpr int kABatch = kDescPerWave < 8 ? kDescPerWave : 8;
+    for (int q0 = 0; q0 < cnt; q0 += kABatch) {
+        uint4 px4[kABatch];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            s1 = (int)__builtin_amdgcn_udot4(px[d], ic_w1[d], (uint32_t)s1, false);
-            su = (int)__builtin_amdgcn_udot4(px[d], ic_wu[d], (uint32_t)su, false);
+        for (int q = 0; q < kABatch; ++q) {
+            px4[q] = make_uint4(0, 0, 0, 0);
+            if (q0 + q < cnt) px4[q] = *reinterpret_cast<const uint4_unaligned*>(patch_ptr(wave + 4 * (q0 + q)) + ic_off);
         }
-        int m10 = su - 16 * s1, m01 = ic_v * s1;
-        m10 = wave_sum_to_lane63(m10);
-        m01 = wave_sum_to_lane63(m01);
-        if (lane == 63) {
-            s_m10[kp0 + q] = m10;
-            s_m01[kp0 + q] = m01;
+#pragma unroll
+        for (int q = 0; q < kABatch; ++q) {
+            if (q0 + q >= cnt) break;
+            const uint32_t px[4] = {px4[q].x, px4[q].y, px4[q].z, px4[q].w};
+            int su = 0, s1 = 0;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                s1 = (int)__builtin_amdgcn_udot4(px[d], ic_w1[d], (uint32_t)s1, false);
+                su = (int)__builtin_amdgcn_udot4(px[d], ic_wu[d], (uint32_t)su, false);
+            }
+            int m10 = su - 16 * s1, m01 = ic_v * s1;
+            m10 = wave_sum_to_lane63(m10);
+            m01 = wave_sum_to_lane63(m01);
+            if (lane == 63) {
+                s_m10[wave + 4 * (q0 + q)] = m10;
+                s_m01[wave + 4 * (q0 + q)] = m01;
+            }
         }
     }
     __syncthreads();
+    ORBX_STAMP_D(B, 1, t0);
 
     // ---- B. angle, rotation, keypoint record: one thread per keypoint ----
     if (tid < nk) {
@@ -215,6 +244,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(BatchDev B, const uint3
         }
     }
     __syncthreads();
+    ORBX_STAMP_D(B, 2, t0);
 
     // ---- C. rotated BRIEF tests on the blurred level ----
     // The 37x37 neighbourhood the rotated pattern can reach (|coordinate| <= 18) is copied to LDS
@@ -238,15 +268,15 @@ __global__ __launch_bounds__(256) void k_orient_describe(BatchDev B, const uint3
 #pragma unroll
         for (int t = 0; t < kPatchLoads; ++t) reg[t] = *reinterpret_cast<const desc_u32_unaligned*>(cb + pr_off[t]);
     };
-    const int cnt_c = max(0, min(cnt, kp_cap - (base_out + kp0)));
+    const int cnt_c = max(0, (min(nk, kp_cap - base_out) - wave + 3) >> 2);  // keypoints beyond the caller's capacity are dropped
     uint32_t nreg[kPatchLoads];
-    if (cnt_c > 0) fetch(kp0, nreg);
+    if (cnt_c > 0) fetch(wave, nreg);
     for (int q = 0; q < cnt_c; ++q) {
-        const int kp = kp0 + q;
+        const int kp = wave + 4 * q;
         __builtin_amdgcn_wave_barrier();  // the previous keypoint's LDS reads are done (same wave, in order)
 #pragma unroll
         for (int t = 0; t < kPatchLoads; ++t) *reinterpret_cast<uint32_t*>(my_patch + pr_lds[t]) = nreg[t];
-        if (q + 1 < cnt_c) fetch(kp + 1, nreg);
+        if (q + 1 < cnt_c) fetch(kp + 4, nreg);
         __builtin_amdgcn_wave_barrier();
         const float a = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_a[kp])));
         const float b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_b[kp])));
@@ -266,6 +296,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(BatchDev B, const uint3
         uint8_t* dsc = out_desc + ((uint64_t)frame * kp_cap + base_out + kp) * 32;
         if ((lane & 1) == 0) dsc[lane >> 1] = (uint8_t)(bits | (other << 4));
     }
+    ORBX_STAMP_D(B, 3, t0);
 }
 
 }  // namespace orbx

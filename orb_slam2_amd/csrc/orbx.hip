@@ -352,7 +352,7 @@ void fill_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_p
     B.kp_total = c->kp_total;
     B.ini_th = c->prm.ini_th_fast;
     B.min_th = c->prm.min_th_fast;
-#ifdef ORBX_STAMPS
+#if defined(ORBX_STAMPS) || defined(ORBX_STAMPS_DESC)
     if (!c->d_stamps.p && ensure(c, &c->d_stamps, 1024 * 16 * 8) == ORBX_OK) (void)hipMemset(c->d_stamps.p, 0, 1024 * 16 * 8);
     B.stamps = (unsigned long long*)c->d_stamps.p;
 #endif
@@ -796,7 +796,7 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->prm.device_id);
     if (c->stream) (void)sync_ctx(c);
-#ifdef ORBX_STAMPS
+#if defined(ORBX_STAMPS) || defined(ORBX_STAMPS_DESC)
     if (c->d_stamps.p) {
         std::vector<unsigned long long> h(1024 * 16);
         if (hipMemcpy(h.data(), c->d_stamps.p, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
