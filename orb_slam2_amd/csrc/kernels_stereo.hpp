@@ -6,7 +6,7 @@
 //   k_stereo_search  eight lanes per left keypoint: Hamming search over the buckets that can
 //                    hold its row (:523-568), then the 11x11 sliding-window distance over
 //                    11 shifts and the parabola fit (:570-642);
-//   k_stereo_cut     median of the accepted window distances and the 1.5*1.4*median cut
+//   k_stereo_cut     median of the accepted window distances (radix select) and the 1.5*1.4*median cut
 //                    (:645-658).
 // Every float statement is evaluated as written in the reference (no contraction), so the
 // results equal the CPU restatement's bit for bit.
@@ -342,6 +342,7 @@ __global__ __launch_bounds__(256) void k_stereo_search(StereoDev S) {
 __global__ __launch_bounds__(1024) void k_stereo_cut(StereoDev S) {
     extern __shared__ __attribute__((aligned(16))) int32_t s_sad[];
     __shared__ int s_count, s_median;
+    __shared__ int s_hist[16][16];
     const int tid = threadIdx.x, p = blockIdx.x;
     const int n = min(S.n_l[(int64_t)p * S.n_step], S.kp_cap);
     const int n4 = (n + 3) & ~3;
@@ -360,22 +361,38 @@ __global__ __launch_bounds__(1024) void k_stereo_cut(StereoDev S) {
     if (mine) atomicAdd(&s_count, mine);
     __syncthreads();
     const int m = s_count;
+    __syncthreads();  // every thread has read the count before thread 0 re-uses the variable
     if (m == 0) return;  // nothing was matched
-    const int k = m / 2;  // vDistIdx[size / 2] of the sorted list (:646)
-    const int4* s4 = reinterpret_cast<const int4*>(s_sad);
-    for (int i = tid; i < n; i += 1024) {
-        const int v = s_sad[i];
-        if (v < 0) continue;
-        int less = 0, leq = 0;
-        for (int j = 0; j < n4 >> 2; ++j) {
-            const int4 t = s4[j];
-            // unmatched entries are -1: never >= 0, so they are masked by the (t >= 0) terms
-            less += (t.x >= 0 && t.x < v) + (t.y >= 0 && t.y < v) + (t.z >= 0 && t.z < v) + (t.w >= 0 && t.w < v);
-            leq += (t.x >= 0 && t.x <= v) + (t.y >= 0 && t.y <= v) + (t.z >= 0 && t.z <= v) + (t.w >= 0 && t.w <= v);
-        }
-        if (less <= k && k < leq) s_median = v;  // every writer holds the same value
+    // vDistIdx[size / 2] of the sorted list (:646): radix select, most significant digit first, four
+    // passes of four bits (a window distance is at most 121 * 510 < 2^16).  Each pass counts, per
+    // digit value, the accepted distances that match the digits chosen so far (one histogram per
+    // wave, LDS atomics), then thread 0 walks the 16 totals to the digit that holds rank k.
+    if (tid == 0) {
+        s_count = m / 2;  // rank still to be skipped inside the current prefix
+        s_median = 0;     // digits chosen so far
     }
-    __syncthreads();
+    for (int shift = 12; shift >= 0; shift -= 4) {
+        if (tid < 256) s_hist[tid >> 4][tid & 15] = 0;
+        __syncthreads();
+        const int prefix = s_median;
+        for (int i = tid; i < n; i += 1024) {
+            const int v = s_sad[i];
+            if (v >= 0 && (v >> (shift + 4)) == prefix) atomicAdd(&s_hist[tid >> 6][(v >> shift) & 15], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int k = s_count, d = 0;
+            for (; d < 15; ++d) {
+                int c = 0;
+                for (int w = 0; w < 16; ++w) c += s_hist[w][d];
+                if (k < c) break;
+                k -= c;
+            }
+            s_count = k;
+            s_median = (prefix << 4) | d;
+        }
+        __syncthreads();
+    }
     const float th = __fmul_rn(1.5f * 1.4f, (float)s_median);  // :647
     for (int i = tid; i < n; i += 1024) {
         const int v = s_sad[i];
