@@ -65,7 +65,7 @@ __host__ __device__ inline size_t oct_lds_bytes(int max_slots, int max_kp, int n
     return (node > pro ? node : pro) + 64;
 }
 
-// grid = (nlevels, frames), block = 256, dynamic LDS = max over levels of oct_lds_bytes.
+// grid = (frames, nlevels), block = 256, dynamic LDS = max over levels of oct_lds_bytes.
 __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __restrict__ cand,
                                                 const uint32_t* __restrict__ ccount,
                                                 uint32_t* __restrict__ dense_pts, uint16_t* __restrict__ dense_node,
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
     __shared__ int s_i[8];  // 0: jcut, 1: nToExpand, 2: finished, 3: careful
 
     const int tid = threadIdx.x;
-    const int level = blockIdx.x, frame = blockIdx.y;
+    const int level = blockIdx.y, frame = blockIdx.x;  // level-major launch order: the levels with the most work start first
     const LevelDev& L = B.lv[level];
     const int N = L.quota;
     unsigned long long t0 = 0;

@@ -502,7 +502,7 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     // stage 2 (main): quadtree retention; it overwrites the retained points of set kp_set, which the
     // descriptor stage of the batch before the previous one may still be reading
     if (overlap && c->desc_pending[kp_set]) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_desc[kp_set], 0));
-    hipLaunchKernelGGL(k_octree, dim3(L, n), dim3(256), c->oct_lds, st, B, (const uint32_t*)c->d_cand.p,
+    hipLaunchKernelGGL(k_octree, dim3(n, L), dim3(256), c->oct_lds, st, B, (const uint32_t*)c->d_cand.p,
                        (const uint32_t*)c->d_ccount.p, (uint32_t*)c->d_dense_pts.p, (uint16_t*)c->d_dense_node.p,
                        (uint32_t*)c->d_lvl_kps[kp_set].p, (int32_t*)c->d_lvl_count[kp_set].p);
     if ((rc = mark(kEvOct1, st))) return rc;
