@@ -78,6 +78,50 @@ __device__ __forceinline__ int wave_sum_to_lane63(int v) {
 
 typedef u32_unaligned desc_u32_unaligned;
 
+// Lane constants of the kernel, the same for every workgroup: built once on the host and loaded as
+// kDescTabVec 16-byte vectors per lane (vector v of lane l at tab[v * 64 + l]).
+//   v0  wu[4]   phase A weight dwords u + 16 inside the disc, 0 outside      (lane = (row, half))
+//   v1  w1[4]   phase A weight dwords 1 inside the disc, 0 outside
+//   v2  v, column offset 16 * half - 15, 0, 0                                (v = row - 15)
+//   v3, v4      x of the lane's eight pattern points (float32 bits)          (tests 4l .. 4l + 3)
+//   v5, v6      y of the same points
+//   v7, v8      six patch-staging entries: LDS offset | (row - 18) << 16 | (4 * dword - 18) << 24
+constexpr int kDescTabVec = 9;
+inline void build_describe_lane_table(const int8_t* pattern /* 512 (x, y) pairs */, uint32_t* tab /* [9][64][4] */) {
+    // Row half-widths of the radius-15 disc (reference src/ORBextractor.cc:473-493).
+    const int umax_tab[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    for (int lane = 0; lane < 64; ++lane) {
+        uint32_t v[kDescTabVec][4] = {};
+        const int row = lane >> 1, half = lane & 1, vv = row - 15;
+        if (row < 31) {
+            const int um = umax_tab[vv < 0 ? -vv : vv];
+            for (int d = 0; d < 4; ++d)
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int u = 16 * half + 4 * d + bb - 15;
+                    if ((u < 0 ? -u : u) <= um) {
+                        v[0][d] |= (uint32_t)(u + 16) << (8 * bb);
+                        v[1][d] |= 1u << (8 * bb);
+                    }
+                }
+            v[2][0] = (uint32_t)vv;
+            v[2][1] = (uint32_t)(16 * half - 15);
+        }
+        for (int e = 0; e < 8; ++e) {
+            const float fx = (float)pattern[16 * lane + 2 * e], fy = (float)pattern[16 * lane + 2 * e + 1];
+            std::memcpy(&v[3 + e / 4][e % 4], &fx, 4);
+            std::memcpy(&v[5 + e / 4][e % 4], &fy, 4);
+        }
+        for (int t = 0; t < 6; ++t) {
+            int it = lane + 64 * t;
+            if (it > 37 * 10 - 1) it = 37 * 10 - 1;
+            const int r = it / 10, k = it - r * 10;
+            v[7 + t / 4][t % 4] = (uint32_t)(r * 40 + 4 * k) | ((uint32_t)((r - 18) & 0xFF) << 16) | ((uint32_t)((4 * k - 18) & 0xFF) << 24);
+        }
+        for (int q = 0; q < kDescTabVec; ++q)
+            for (int d = 0; d < 4; ++d) tab[(q * 64 + lane) * 4 + d] = v[q][d];
+    }
+}
+
 // Diagnostic build only (-DORBX_STAMPS_DESC): wave 0 adds the cycles between phase boundaries into
 // B.stamps[slot] (1024 copies spread by block id); the product build compiles these calls away.
 #ifdef ORBX_STAMPS_DESC
@@ -106,7 +150,7 @@ typedef u32_unaligned desc_u32_unaligned;
 // grid = 8 * ceil(frames/8) * nlevels * kp_blocks (1-D), block = 256.
 __global__ __launch_bounds__(256) void k_orient_describe(BatchDev B, const uint32_t* __restrict__ lvl_kps,
                                                          const int32_t* __restrict__ lvl_count,
-                                                         const int8_t* __restrict__ pattern, // 512 (x, y) pairs
+                                                         const uint4* __restrict__ lane_tab,  // build_describe_lane_table
                                                          orbx_kp* __restrict__ out_kps, uint8_t* __restrict__ out_desc,
                                                          int32_t* __restrict__ out_n, int kp_cap, int kp_blocks) {
     __shared__ uint32_t s_pk[kDescKp];
@@ -140,43 +184,21 @@ __global__ __launch_bounds__(256) void k_orient_describe(BatchDev B, const uint3
 #endif
     if (tid < nk) s_pk[tid] = lvl_kps[(uint64_t)frame * B.kp_total + L.kp_off + first + tid];
 
-    // ---- lane constants of phase A: four patch dwords (row, dword-of-row) and their weights ----
-    // Row half-widths of the radius-15 disc (reference src/ORBextractor.cc:473-493).
-    const int umax_tab[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-    // lane = (row, half): bytes u = -15 + 16*half .. +15 of patch row v = row - 15
-    int ic_off = 0, ic_v = 0;
-    uint32_t ic_wu[4] = {0, 0, 0, 0}, ic_w1[4] = {0, 0, 0, 0};
-    {
-        const int row = lane >> 1, half = lane & 1, vv = row - 15;
-        if (row < 31) {
-            int um = 0;
+    // ---- lane constants (see build_describe_lane_table) ----
+    uint4 tv[kDescTabVec];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) um = (abs(vv) == q) ? umax_tab[q] : um;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-#pragma unroll
-                for (int bb = 0; bb < 4; ++bb) {
-                    const int u = 16 * half + 4 * d + bb - 15;
-                    if (abs(u) <= um) {
-                        ic_wu[d] |= (uint32_t)(u + 16) << (8 * bb);
-                        ic_w1[d] |= 1u << (8 * bb);
-                    }
-                }
-            }
-            ic_v = vv;
-            ic_off = vv * L.pitch + 16 * half - 15;
-        }
-    }
-    // ---- lane constants of phase C: the eight pattern points of tests 4*lane .. 4*lane+3 ----
-    float pat_x[8], pat_y[8];
-    {
-        const int8_t* pp = pattern + 16 * lane;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            pat_x[e] = (float)pp[2 * e];
-            pat_y[e] = (float)pp[2 * e + 1];
-        }
-    }
+    for (int q = 0; q < kDescTabVec; ++q) tv[q] = lane_tab[q * 64 + lane];
+    const uint32_t ic_wu[4] = {tv[0].x, tv[0].y, tv[0].z, tv[0].w}, ic_w1[4] = {tv[1].x, tv[1].y, tv[1].z, tv[1].w};
+    // the patch offset is computed, not loaded, so that the patch loads do not wait for the table
+    const int ic_v = lane < 62 ? (lane >> 1) - 15 : 0;
+    const int ic_off = lane < 62 ? ic_v * L.pitch + 16 * (lane & 1) - 15 : 0;  // lanes 62, 63: no row 31, weights 0
+    const float pat_x[8] = {__builtin_bit_cast(float, tv[3].x), __builtin_bit_cast(float, tv[3].y), __builtin_bit_cast(float, tv[3].z),
+                            __builtin_bit_cast(float, tv[3].w), __builtin_bit_cast(float, tv[4].x), __builtin_bit_cast(float, tv[4].y),
+                            __builtin_bit_cast(float, tv[4].z), __builtin_bit_cast(float, tv[4].w)};
+    const float pat_y[8] = {__builtin_bit_cast(float, tv[5].x), __builtin_bit_cast(float, tv[5].y), __builtin_bit_cast(float, tv[5].z),
+                            __builtin_bit_cast(float, tv[5].w), __builtin_bit_cast(float, tv[6].x), __builtin_bit_cast(float, tv[6].y),
+                            __builtin_bit_cast(float, tv[6].z), __builtin_bit_cast(float, tv[6].w)};
+    const uint32_t pr_tab[8] = {tv[7].x, tv[7].y, tv[7].z, tv[7].w, tv[8].x, tv[8].y, tv[8].z, tv[8].w};
     __syncthreads();
     ORBX_STAMP_D(B, 0, t0);
 
@@ -257,10 +279,9 @@ __global__ __launch_bounds__(256) void k_orient_describe(BatchDev B, const uint3
     int pr_off[kPatchLoads], pr_lds[kPatchLoads];
 #pragma unroll
     for (int t = 0; t < kPatchLoads; ++t) {
-        const int it = min(lane + 64 * t, kPatchRows * kPatchDw - 1);
-        const int r = (int)(((float)it + 0.5f) * (1.0f / (float)kPatchDw)), k = it - r * kPatchDw;
-        pr_off[t] = (r - 18) * bp + 4 * k - 18;
-        pr_lds[t] = r * kPatchPitch + 4 * k;
+        const uint32_t e = pr_tab[t];
+        pr_off[t] = ((int)(e << 8) >> 24) * bp + ((int)e >> 24);  // (row - 18) * pitch + 4 * dword - 18
+        pr_lds[t] = (int)(e & 0xFFFFu);
     }
     auto fetch = [&](int kp, uint32_t (&reg)[kPatchLoads]) {
         const uint32_t pk = __builtin_amdgcn_readfirstlane(s_pk[kp]);

@@ -525,7 +525,7 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
         const int kp_blocks = (c->max_kp_level + kDescKp - 1) / kDescKp;
         const unsigned grid = 8u * (unsigned)((n + 7) / 8) * (unsigned)L * (unsigned)kp_blocks;
         hipLaunchKernelGGL(k_orient_describe, dim3(grid), dim3(256), 0, sd, B, (const uint32_t*)c->d_lvl_kps[kp_set].p,
-                           (const int32_t*)c->d_lvl_count[kp_set].p, (const int8_t*)c->d_pat.p, d_kps, d_desc, d_n_out, kp_cap,
+                           (const int32_t*)c->d_lvl_count[kp_set].p, (const uint4*)c->d_pat.p, d_kps, d_desc, d_n_out, kp_cap,
                            kp_blocks);
     }
     if ((rc = mark(kEvDesc1, sd))) return rc;
@@ -779,8 +779,12 @@ extern "C" int orbx_create(const orbx_params* params, orbx_ctx** out) {
     for (int i = 0; i < kEvCount; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(ORBX_E_HIP);
     c->ev_made = true;
-    if ((rc = ensure(c, &c->d_pat, sizeof(kPattern)))) return fail(rc);
-    if (hipMemcpy(c->d_pat.p, kPattern, sizeof(kPattern), hipMemcpyHostToDevice) != hipSuccess) return fail(ORBX_E_HIP);
+    {
+        std::vector<uint32_t> tab((size_t)kDescTabVec * 64 * 4);
+        build_describe_lane_table(kPattern, tab.data());
+        if ((rc = ensure(c, &c->d_pat, tab.size() * 4))) return fail(rc);
+        if (hipMemcpy(c->d_pat.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(ORBX_E_HIP);
+    }
     // size everything for the largest image and batch now, so steady-state calls do not allocate
     if ((rc = set_geometry(c, params->max_width, params->max_height))) return fail(rc);
     if ((rc = ensure_arenas(c, params->max_batch, true))) return fail(rc);
