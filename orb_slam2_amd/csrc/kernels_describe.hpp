@@ -301,14 +301,19 @@ __global__ __launch_bounds__(256) void k_orient_describe(BatchDev B, const uint3
         __builtin_amdgcn_wave_barrier();
         const float a = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_a[kp])));
         const float b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_b[kp])));
-        const uint8_t* pc = my_patch + 18 * kPatchPitch + 18;
+        // cvRound = round half to even.  Adding 1.5 * 2^23 rounds a float of magnitude below 2^22 to
+        // that integer in its low mantissa bits: the sum's bit pattern is 0x4B400000 + n, so
+        // row * pitch + col is one 24-bit multiply-add of the two bit patterns plus a folded constant.
+        const float kMagic = 12582912.0f;
+        // (unsigned arithmetic: the intermediate terms wrap, the final index is the small true one)
+        const uint32_t kFold = (uint32_t)(18 * kPatchPitch + 18) - (0x400000u * (uint32_t)kPatchPitch + 0x4B400000u);
         int val[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             // the reference's -march=native build contracts x*b + y*a and x*a - y*b into one fma
-            const int row = (int)rintf(__fmaf_rn(pat_x[e], b, __fmul_rn(pat_y[e], a)));
-            const int col = (int)rintf(__fmaf_rn(pat_x[e], a, -__fmul_rn(pat_y[e], b)));
-            val[e] = pc[row * kPatchPitch + col];
+            const float fr = __fadd_rn(__fmaf_rn(pat_x[e], b, __fmul_rn(pat_y[e], a)), kMagic);
+            const float fc = __fadd_rn(__fmaf_rn(pat_x[e], a, -__fmul_rn(pat_y[e], b)), kMagic);
+            val[e] = my_patch[(uint32_t)__mul24(__builtin_bit_cast(int, fr), kPatchPitch) + __builtin_bit_cast(uint32_t, fc) + kFold];
         }
         uint32_t bits = 0;
 #pragma unroll
