@@ -182,14 +182,13 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
     // ---- 1. rejection test, four pixels per work item, two pixels per instruction ----
     // Any arc of 9 holds one pixel of each opposite pair, so a corner needs the two compass pairs
     // (up/down, left/right) to each hold a pixel beyond the threshold on the same side.  The
-    // dword's bytes are split into even and odd pixels as two 16-bit lanes; with the centre biased
-    // by 256 a plain 32-bit subtract yields both lanes' differences, packed u16 min/max combine
-    // the pairs, and adding a constant moves "beyond the threshold" into bit 15 of each lane.
+    // dword's bytes are split into even and odd pixels as two 16-bit lanes; packed u16 min/max
+    // combine the ring pixels of the pairs, and one biased 32-bit subtract per polarity against the
+    // centre moves "beyond the threshold" into bit 15 of each lane.
     // Pixels whose ring is darker go to the front of the queue, brighter ones to its back, so that
     // step 2 runs each half of the score on a dense range.
     const int ndwd = (wd + 3) >> 2, n_items = hd * ndwd;
-    const uint32_t add_bright = (uint32_t)(0x8000 - 257 - thr) * 0x00010001u;
-    const uint32_t sub_dark = (uint32_t)(0x8000 + 255 - thr) * 0x00010001u;
+    const uint32_t k_thr = (uint32_t)(0x8000 - 1 - thr) * 0x00010001u;
     // (row, dword) of item tid, advanced by 256 items per iteration without divisions
     int v = (int)(((float)tid + 0.5f) * (1.0f / (float)ndwd));
     int j = tid - v * ndwd;
@@ -218,14 +217,17 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
             for (int h2 = 0; h2 < 2; ++h2) {  // 0: pixels 0,2   1: pixels 1,3
                 // one v_perm_b32 spreads two bytes over the 16-bit lanes; the centre takes its bias
                 // (high byte 1) from the second operand
-                const uint32_t sel_c = h2 ? 0x04030401u : 0x04020400u, sel_r = h2 ? 0x0C030C01u : 0x0C020C00u;
-                const uint32_t c = __builtin_amdgcn_perm(0x01010101u, Cd, sel_c);
-                const uint32_t d0 = c - __builtin_amdgcn_perm(0u, Ud, sel_r), d8 = c - __builtin_amdgcn_perm(0u, Dd, sel_r);
-                const uint32_t d4 = c - __builtin_amdgcn_perm(0u, Rd, sel_r), d12 = c - __builtin_amdgcn_perm(0u, Ld, sel_r);
-                const uint32_t br = pk_min_u16(pk_max_u16(d0, d8), pk_max_u16(d4, d12));
-                const uint32_t dk = pk_max_u16(pk_min_u16(d0, d8), pk_min_u16(d4, d12));
-                pb[h2] = br + add_bright;  // only bits 15 and 31 are read
-                pd[h2] = sub_dark - dk;
+                const uint32_t sel = h2 ? 0x0C030C01u : 0x0C020C00u;
+                const uint32_t c = __builtin_amdgcn_perm(0u, Cd, sel);
+                const uint32_t u = __builtin_amdgcn_perm(0u, Ud, sel), d = __builtin_amdgcn_perm(0u, Dd, sel);
+                const uint32_t r = __builtin_amdgcn_perm(0u, Rd, sel), l = __builtin_amdgcn_perm(0u, Ld, sel);
+                // ring darker on both pairs: centre - max(min(u,d), min(l,r)) > t; ring brighter:
+                // min(max(u,d), max(l,r)) - centre > t.  With k = 0x8000 - 1 - t added to the minuend the
+                // verdict is bit 15 of each lane, and no lane borrows from its neighbour.
+                const uint32_t hi = pk_max_u16(pk_min_u16(u, d), pk_min_u16(l, r));
+                const uint32_t lo = pk_min_u16(pk_max_u16(u, d), pk_max_u16(l, r));
+                pb[h2] = (c + k_thr) - hi;  // only bits 15 and 31 are read
+                pd[h2] = (lo + k_thr) - c;
                 if (RETRY) {
                     pb[h2] &= on[h2];
                     pd[h2] &= on[h2];
