@@ -167,6 +167,43 @@ int orbx_undistort_grid_batch_device(orbx_ctx* ctx, int n, const orbx_kp* d_kps,
                                      orbx_kp* d_kps_un, int32_t* d_cell_start, int32_t* d_cell_idx,
                                      int sync);
 
+/* ---- descriptor consumer: the bag-of-words transform -------------------------------------
+ * Replaces Frame::ComputeBoW (reference src/Frame.cc:411-418), i.e.
+ * ORBVocabulary::transform(descriptors, mBowVec, mFeatVec, 4) of the vendored DBoW2 (reference
+ * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1194; one feature down the tree :1218-1260;
+ * FORB::distance, FORB.cpp:81-101; BowVector.cpp:25-84; FeatureVector.cpp:31-45), for every frame
+ * of a batch whose descriptors are in device memory.
+ *
+ * A vocabulary is a tree: node 0 is the root, node i > 0 has parent[i] < i, a 32-byte centre, a
+ * weight and the is-leaf flag of its line in the text file; word ids go to the flagged nodes in
+ * node order, children keep node order (loadFromTextFile, :1338-1425).  scoring / weighting are
+ * the header's enum values (ORBvoc.txt: "10 6 0 0" = k, L, L1_NORM, TF_IDF). */
+typedef struct orbx_voc orbx_voc;
+int orbx_voc_create(int k, int L, int scoring, int weighting, int n_nodes, const int32_t* parent,
+                    const uint8_t* is_leaf, const uint8_t* desc /* n_nodes x 32 */,
+                    const double* weight, orbx_voc** out);
+/* The text format ORB_SLAM2 ships its vocabulary in (System.cc loads it with loadFromTextFile). */
+int orbx_voc_load_text(const char* path, orbx_voc** out);
+void orbx_voc_destroy(orbx_voc* voc);
+int orbx_voc_info(const orbx_voc* voc, int* k, int* L, int* n_nodes, int* n_words);
+/* One node of the tree as the library holds it (host side): number of children, the first child's
+ * node id (0 if none), centre, weight, word id.  For checking a loaded file. */
+int orbx_voc_node(const orbx_voc* voc, int node, int* n_children, uint32_t* first_child, uint8_t desc[32],
+                  double* weight, uint32_t* word);
+/* d_desc[n][kp_cap][32], d_n[n]: as the extractor's batch entry points leave them.  Per feature
+ * (arrays of n*kp_cap): d_word, d_node (the node met at level L - levelsup; 0 when that level is
+ * not positive or the leaf is met earlier), d_weight.  Per frame f: the BowVector in word order in
+ * d_bow_id / d_bow_val[f*kp_cap .. + d_bow_n[f]) and the FeatureVector as (node, feature index)
+ * pairs, nodes ascending and indices ascending inside a node, in d_fv_node / d_fv_idx[f*kp_cap
+ * .. + d_fv_n[f]).  Features whose word weight is 0 (stopped words) are left out of both, as in
+ * the reference.  kp_cap <= 16384.  The vocabulary is copied to the context's device on first
+ * use and stays there. */
+int orbx_bow_transform_batch_device(orbx_ctx* ctx, orbx_voc* voc, int n, const uint8_t* d_desc, int kp_cap,
+                                    const int32_t* d_n, int levelsup, uint32_t* d_word, uint32_t* d_node,
+                                    double* d_weight, uint32_t* d_bow_id, double* d_bow_val, int32_t* d_bow_n,
+                                    uint32_t* d_fv_node, uint32_t* d_fv_idx, int32_t* d_fv_n, int sync);
+
+
 /* ---- the stage after the extractor: stereo association ---------------------------------
  * Replaces Frame::ComputeStereoMatches (reference src/Frame.cc:485-659, descriptor distance
  * src/ORBmatcher.cc:1684-1700): for every left keypoint the best right keypoint in its row

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <map>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -1063,4 +1064,127 @@ extern "C" void orc_assign_grid(const float* xy, int n, float min_x, float min_y
         for (size_t k = 0; k < grid[c].size(); k++) idx[at++] = grid[c][k];
     }
     cell_start[COLS * ROWS] = at;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bag-of-words transform (reference Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1260).
+struct orc_voc {
+    struct Node {
+        std::vector<uint32_t> children;
+        uint8_t desc[32];
+        double weight;
+        uint32_t word_id;
+    };
+    int k, L, scoring, weighting;
+    std::vector<Node> nodes;
+    int n_words;
+};
+
+extern "C" orc_voc* orc_voc_create(int k, int L, int scoring, int weighting, int n_nodes, const int32_t* parent,
+                                   const uint8_t* is_leaf, const uint8_t* desc, const double* weight) {
+    if (n_nodes < 1 || L < 1 || scoring < 0 || scoring > 5 || weighting < 0 || weighting > 3) return nullptr;
+    orc_voc* v = new orc_voc;
+    v->k = k;
+    v->L = L;
+    v->scoring = scoring;
+    v->weighting = weighting;
+    v->nodes.resize((size_t)n_nodes);
+    v->n_words = 0;
+    for (int i = 0; i < n_nodes; ++i) {
+        orc_voc::Node& nd = v->nodes[(size_t)i];
+        std::memcpy(nd.desc, desc + (size_t)i * 32, 32);
+        nd.weight = weight[i];
+        nd.word_id = 0;
+        if (i == 0) continue;  // the root has no line in the file
+        if (parent[i] < 0 || parent[i] >= i) {
+            delete v;
+            return nullptr;
+        }
+        v->nodes[(size_t)parent[i]].children.push_back((uint32_t)i);  // :1390-1391
+        if (is_leaf[i]) nd.word_id = (uint32_t)v->n_words++;           // :1408-1415
+    }
+    return v;
+}
+extern "C" void orc_voc_destroy(orc_voc* v) { delete v; }
+extern "C" int orc_voc_num_words(const orc_voc* v) { return v->n_words; }
+
+extern "C" void orc_voc_transform_feature(const orc_voc* v, const uint8_t desc[32], int levelsup, uint32_t* word,
+                                          uint32_t* node, double* weight) {
+    const int nid_level = v->L - levelsup;  // :1226
+    uint32_t nid = 0, final_id = 0;
+    int current_level = 0;
+    if (!v->nodes[0].children.empty()) {
+        do {  // :1232-1254
+            ++current_level;
+            const std::vector<uint32_t>& ch = v->nodes[final_id].children;
+            final_id = ch[0];
+            double best_d = (double)orc_descriptor_distance(desc, v->nodes[final_id].desc);
+            for (size_t c = 1; c < ch.size(); ++c) {
+                const double d = (double)orc_descriptor_distance(desc, v->nodes[ch[c]].desc);
+                if (d < best_d) {
+                    best_d = d;
+                    final_id = ch[c];
+                }
+            }
+            if (current_level == nid_level) nid = final_id;
+        } while (!v->nodes[final_id].children.empty());
+    }
+    *word = v->nodes[final_id].word_id;  // :1257-1258
+    *weight = v->nodes[final_id].weight;
+    *node = nid;
+}
+
+extern "C" void orc_voc_transform(const orc_voc* v, const uint8_t* descs, int n, int levelsup, uint32_t* bow_id,
+                                  double* bow_val, int* n_bow, uint32_t* fv_node, uint32_t* fv_idx, int* n_fv) {
+    std::map<uint32_t, double> bow;
+    std::map<uint32_t, std::vector<uint32_t>> fv;
+    // L1 for every scoring but L2_NORM; DOT_PRODUCT does not normalise (ScoringObject.h:73-90)
+    const bool must = v->scoring != 5, l2 = v->scoring == 1;
+    const bool sums = v->weighting == 0 || v->weighting == 1;  // TF_IDF, TF: addWeight; IDF, BINARY: addIfNotExist
+    if (!v->nodes[0].children.empty()) {  // empty(): nothing is produced (:1133-1136)
+        for (int i = 0; i < n; ++i) {
+            uint32_t id, nid;
+            double w;
+            orc_voc_transform_feature(v, descs + (size_t)i * 32, levelsup, &id, &nid, &w);
+            if (w > 0) {  // :1157, :1185
+                auto it = bow.lower_bound(id);
+                if (it != bow.end() && it->first == id) {
+                    if (sums) it->second += w;
+                } else {
+                    bow.insert(it, std::make_pair(id, w));
+                }
+                fv[nid].push_back((uint32_t)i);
+            }
+        }
+        if (sums && !bow.empty() && !must) {  // :1164-1170
+            const double nd = (double)bow.size();
+            for (auto& e : bow) e.second /= nd;
+        }
+        if (must) {  // BowVector::normalize, BowVector.cpp:62-84
+            double norm = 0.0;
+            if (!l2) {
+                for (auto& e : bow) norm += std::fabs(e.second);
+            } else {
+                for (auto& e : bow) norm += e.second * e.second;
+                norm = std::sqrt(norm);
+            }
+            if (norm > 0.0)
+                for (auto& e : bow) e.second /= norm;
+        }
+    }
+    int nb = 0;
+    for (auto& e : bow) {
+        bow_id[nb] = e.first;
+        bow_val[nb] = e.second;
+        ++nb;
+    }
+    *n_bow = nb;
+    int nf = 0;
+    for (auto& e : fv)
+        for (uint32_t i : e.second) {
+            fv_node[nf] = e.first;
+            fv_idx[nf] = i;
+            ++nf;
+        }
+    *n_fv = nf;
 }

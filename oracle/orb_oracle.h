@@ -156,6 +156,34 @@ void orc_undistort_points(const float* xy_in, int n, const float K[4], const flo
 void orc_assign_grid(const float* xy, int n, float min_x, float min_y, float inv_w, float inv_h,
                      int32_t* cell_start, int32_t* idx);
 
+/* ---- descriptor consumer: the bag-of-words transform ---------------------------------------- */
+/* Frame::ComputeBoW (reference src/Frame.cc:411-418) = TemplatedVocabulary::transform(features,
+   BowVector&, FeatureVector&, levelsup = 4) of the vendored DBoW2
+   (reference Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1194, per feature :1218-1260;
+   FORB::distance, FORB.cpp:81-101; BowVector::addWeight / addIfNotExist / normalize,
+   BowVector.cpp:25-84; FeatureVector::addFeature, FeatureVector.cpp:31-45).
+   The vocabulary is a tree: node 0 is the root, node i > 0 has parent[i] < i, a 32-byte centre,
+   a weight, and is_leaf[i] as the text file of loadFromTextFile (:1338-1425) states it.  Children
+   are kept in node order (the push_back order); word ids are given to the nodes flagged is_leaf in
+   node order.  scoring / weighting are the file header's enum values (ORBvoc.txt: 0 0 = L1_NORM,
+   TF_IDF).  The ORB-SLAM2 vocabulary file itself is not in the reference checkout; the tests use
+   hand-built and seeded random trees. */
+typedef struct orc_voc orc_voc;
+orc_voc* orc_voc_create(int k, int L, int scoring, int weighting, int n_nodes, const int32_t* parent,
+                        const uint8_t* is_leaf, const uint8_t* desc /* n_nodes x 32 */, const double* weight);
+void orc_voc_destroy(orc_voc* v);
+int orc_voc_num_words(const orc_voc* v);
+/* One feature down the tree (:1218-1260): the child with the smallest Hamming distance at each
+   level, the first one on ties; *node = the node met at level L - levelsup (0 when that level is
+   not positive; the reference leaves it unset when the leaf is met earlier, here it stays 0). */
+void orc_voc_transform_feature(const orc_voc* v, const uint8_t desc[32], int levelsup, uint32_t* word,
+                               uint32_t* node, double* weight);
+/* All n features of a frame (:1127-1194).  bow_id / bow_val: the BowVector in word order (n
+   entries of room); fv_node / fv_idx: the FeatureVector as (node, feature index) pairs in node
+   order, indices ascending inside a node (n entries of room). */
+void orc_voc_transform(const orc_voc* v, const uint8_t* descs, int n, int levelsup, uint32_t* bow_id,
+                       double* bow_val, int* n_bow, uint32_t* fv_node, uint32_t* fv_idx, int* n_fv);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,7 @@ EXPORTS = [
     "orbx_stage_name", "orbx_strerror", "orbx_last_hip_error", "orbx_version",
     "orbx_stereo_match", "orbx_stereo_match_batch_device", "orbx_gray_batch_device", "orbx_remap_batch_device",
     "orbx_undistort_grid_batch_device",
+    "orbx_voc_create", "orbx_voc_load_text", "orbx_voc_destroy", "orbx_voc_info", "orbx_voc_node", "orbx_bow_transform_batch_device",
 ]
 
 _lib = None
@@ -78,6 +79,13 @@ def load_library():
     L.orbx_stereo_match.argtypes = [vp, i32, vp, i32, f32, f32, vp, vp, i32, C.POINTER(i32)]
     L.orbx_stereo_match_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, f32, f32, vp, vp, i32]
     L.orbx_undistort_grid_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, f32, f32, f32, f32, vp, vp, vp, i32]
+    L.orbx_voc_create.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, vp, C.POINTER(vp)]
+    L.orbx_voc_load_text.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.orbx_voc_destroy.argtypes = [vp]
+    L.orbx_voc_destroy.restype = None
+    L.orbx_voc_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.orbx_voc_node.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(C.c_uint32), vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+    L.orbx_bow_transform_batch_device.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]
     L.orbx_gray_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, i32, i32, vp, i32, C.c_size_t, i32]
     L.orbx_remap_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, vp, vp, i32, vp, i32, i32, i32,
                                           C.c_size_t, i32]
@@ -291,6 +299,16 @@ class ORBextractor:
                                                         C.c_void_p(d_cell_start), C.c_void_p(d_cell_idx), int(sync)),
                self._ctx)
 
+    # ---- descriptor consumer: Frame::ComputeBoW (src/Frame.cc:411-418) ----
+    def bow_transform_batch_device(self, voc, n, d_desc, kp_cap, d_n, levelsup, d_word, d_node, d_weight, d_bow_id,
+                                   d_bow_val, d_bow_n, d_fv_node, d_fv_idx, d_fv_n, sync=True):
+        """mBowVec and mFeatVec of every frame of a batch (DBoW2's transform with `levelsup`); `voc` is an
+        ORBVocabulary; raw device addresses; see orbx_bow_transform_batch_device."""
+        _check(self._L.orbx_bow_transform_batch_device(
+            self._ctx, voc._v, n, C.c_void_p(d_desc), kp_cap, C.c_void_p(d_n), levelsup, C.c_void_p(d_word),
+            C.c_void_p(d_node), C.c_void_p(d_weight), C.c_void_p(d_bow_id), C.c_void_p(d_bow_val), C.c_void_p(d_bow_n),
+            C.c_void_p(d_fv_node), C.c_void_p(d_fv_idx), C.c_void_p(d_fv_n), int(sync)), self._ctx)
+
     # ---- the stage after the extractor: Frame::ComputeStereoMatches (src/Frame.cc:485-659) ----
     def stereo_match(self, right, mb, mbf, img_left=0, img_right=0):
         """Associates image `img_left` of this extractor's last host-memory extraction with image
@@ -350,3 +368,53 @@ class ORBextractor:
         ms = np.zeros(NUM_STAGES, np.float32)
         _check(self._L.orbx_get_stage_ms(self._ctx, _ptr(ms)), self._ctx)
         return {self._L.orbx_stage_name(i).decode(): float(ms[i]) for i in range(NUM_STAGES)}
+
+
+class ORBVocabulary:
+    """The vocabulary tree of ORB_SLAM2::ORBVocabulary (DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>,
+    reference include/ORBVocabulary.h) for ORBextractor.bow_transform_batch_device: built from per-node arrays
+    (entry 0 = root) or read from the text file ORB_SLAM2 ships (`ORBVocabulary.load_text`)."""
+
+    def __init__(self, k, L, scoring, weighting, parent, is_leaf, desc, weight, _handle=None):
+        self._L = load_library()
+        if _handle is not None:
+            self._v = _handle
+            return
+        parent = np.ascontiguousarray(parent, np.int32)
+        is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        weight = np.ascontiguousarray(weight, np.float64)
+        n = len(parent)
+        if not (len(is_leaf) == n and len(desc) == n and len(weight) == n):
+            raise OrbxError("vocabulary arrays differ in length")
+        v = C.c_void_p()
+        _check(self._L.orbx_voc_create(k, L, scoring, weighting, n, _ptr(parent), _ptr(is_leaf), _ptr(desc), _ptr(weight),
+                                       C.byref(v)))
+        self._v = v
+
+    @classmethod
+    def load_text(cls, path):
+        L = load_library()
+        v = C.c_void_p()
+        _check(L.orbx_voc_load_text(str(path).encode(), C.byref(v)))
+        return cls(0, 0, 0, 0, None, None, None, None, _handle=v)
+
+    def info(self):
+        k, L, nn, nw = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        _check(self._L.orbx_voc_info(self._v, C.byref(k), C.byref(L), C.byref(nn), C.byref(nw)))
+        return {"k": k.value, "L": L.value, "n_nodes": nn.value, "n_words": nw.value}
+
+    def node(self, i):
+        """(n_children, first_child, centre[32], weight, word id) of node i."""
+        nc, fc, w, wd = C.c_int(0), C.c_uint32(0), C.c_double(0), C.c_uint32(0)
+        d = np.zeros(32, np.uint8)
+        _check(self._L.orbx_voc_node(self._v, i, C.byref(nc), C.byref(fc), _ptr(d), C.byref(w), C.byref(wd)))
+        return nc.value, fc.value, d, w.value, wd.value
+
+    def close(self):
+        if getattr(self, "_v", None):
+            self._L.orbx_voc_destroy(self._v)
+            self._v = None
+
+    def __del__(self):
+        self.close()

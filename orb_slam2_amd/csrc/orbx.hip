@@ -15,6 +15,7 @@
 #include "kernels_fast.hpp"
 #include "kernels_octree.hpp"
 #include "kernels_post.hpp"
+#include "kernels_bow.hpp"
 #include "kernels_pyramid.hpp"
 #include "kernels_staging.hpp"
 #include "kernels_stereo.hpp"
@@ -1034,6 +1035,131 @@ extern "C" int orbx_undistort_grid_batch_device(orbx_ctx* c, int n, const orbx_k
     PostParams P = {K[0], K[1], K[2], K[3], dist[0], dist[1], dist[2], dist[3], dist[4], min_x, min_y, inv_w, inv_h};
     hipLaunchKernelGGL(k_undistort_grid, dim3(n), dim3(256), 0, c->stream, P, d_kps, d_n, kp_cap, d_kps_un, d_cell_start,
                        d_cell_idx);
+    HIP_TRY(c, hipGetLastError());
+    if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
+    return ORBX_OK;
+}
+
+// ---- bag-of-words transform ------------------------------------------------------------------
+struct orbx_voc {
+    VocHost h;
+    int device = -1;  // device the tree has been copied to
+    void *d_rec = nullptr, *d_word = nullptr, *d_weight = nullptr;
+};
+
+extern "C" int orbx_voc_create(int k, int L, int scoring, int weighting, int n_nodes, const int32_t* parent,
+                               const uint8_t* is_leaf, const uint8_t* desc, const double* weight, orbx_voc** out) {
+    if (!parent || !is_leaf || !desc || !weight || !out) return ORBX_E_INVALID;
+    orbx_voc* v = new (std::nothrow) orbx_voc;
+    if (!v) return ORBX_E_INVALID;
+    const int rc = build_vocabulary(k, L, scoring, weighting, n_nodes, parent, is_leaf, desc, weight, &v->h);
+    if (rc) {
+        delete v;
+        return rc;
+    }
+    *out = v;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_voc_load_text(const char* path, orbx_voc** out) {
+    if (!path || !out) return ORBX_E_INVALID;
+    orbx_voc* v = new (std::nothrow) orbx_voc;
+    if (!v) return ORBX_E_INVALID;
+    const int rc = load_vocabulary_text(path, &v->h);
+    if (rc) {
+        delete v;
+        return rc;
+    }
+    *out = v;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_voc_destroy(orbx_voc* v) {
+    if (!v) return;
+    if (v->device >= 0) {
+        (void)hipSetDevice(v->device);
+        for (void* p : {v->d_rec, v->d_word, v->d_weight})
+            if (p) (void)hipFree(p);
+    }
+    delete v;
+}
+
+extern "C" int orbx_voc_info(const orbx_voc* v, int* k, int* L, int* n_nodes, int* n_words) {
+    if (!v) return ORBX_E_INVALID;
+    if (k) *k = v->h.k;
+    if (L) *L = v->h.L;
+    if (n_nodes) *n_nodes = v->h.n_nodes();
+    if (n_words) *n_words = v->h.n_words;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_voc_node(const orbx_voc* v, int node, int* n_children, uint32_t* first_child, uint8_t desc[32],
+                             double* weight, uint32_t* word) {
+    if (!v || node < 0 || node >= v->h.n_nodes()) return ORBX_E_INVALID;
+    const uint32_t s = v->h.child_start[(size_t)node], e = v->h.child_start[(size_t)node + 1];
+    if (n_children) *n_children = (int)(e - s);
+    if (first_child) *first_child = e > s ? v->h.child[s] : 0;
+    if (desc) std::memcpy(desc, v->h.desc.data() + (size_t)node * 32, 32);
+    if (weight) *weight = v->h.weight[(size_t)node];
+    if (word) *word = v->h.word[(size_t)node];
+    return ORBX_OK;
+}
+
+extern "C" int orbx_bow_transform_batch_device(orbx_ctx* c, orbx_voc* v, int n, const uint8_t* d_desc, int kp_cap,
+                                               const int32_t* d_n, int levelsup, uint32_t* d_word, uint32_t* d_node,
+                                               double* d_weight, uint32_t* d_bow_id, double* d_bow_val, int32_t* d_bow_n,
+                                               uint32_t* d_fv_node, uint32_t* d_fv_idx, int32_t* d_fv_n, int sync) {
+    if (!c || !v || !d_desc || !d_n || !d_word || !d_node || !d_weight || !d_bow_id || !d_bow_val || !d_bow_n ||
+        !d_fv_node || !d_fv_idx || !d_fv_n || n < 1 || kp_cap < 1 || levelsup < 0)
+        return ORBX_E_INVALID;
+    if (kp_cap > 16384) return ORBX_E_CAPACITY;
+    HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    if (v->device >= 0 && v->device != c->prm.device_id) return ORBX_E_STATE;  // a tree lives on one device
+    if (v->device < 0) {
+        auto up = [&](void** dst, const void* src, size_t bytes) -> int {
+            HIP_TRY(c, hipMalloc(dst, std::max<size_t>(bytes, 16)));
+            HIP_TRY(c, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+            return ORBX_OK;
+        };
+        int rc;
+        v->device = c->prm.device_id;
+        // the children lists as records: centre, node id and the range of the child's own children
+        std::vector<VocRec> rec((size_t)std::max(1, v->h.n_nodes() - 1));
+        for (int pos = 0; pos + 1 < v->h.n_nodes(); ++pos) {
+            const uint32_t id = v->h.child[(size_t)pos];
+            VocRec& r = rec[(size_t)pos];
+            std::memcpy(&r.d0, v->h.desc.data() + (size_t)id * 32, 32);
+            r.id = id;
+            r.begin = v->h.child_start[id];
+            r.end = v->h.child_start[(size_t)id + 1];
+            r.pad = 0;
+        }
+        if ((rc = up(&v->d_rec, rec.data(), rec.size() * sizeof(VocRec)))) return rc;
+        if ((rc = up(&v->d_word, v->h.word.data(), v->h.word.size() * 4))) return rc;
+        if ((rc = up(&v->d_weight, v->h.weight.data(), v->h.weight.size() * 8))) return rc;
+    }
+    { int rc_ = join(c); if (rc_) return rc_; }
+    VocDev V;
+    V.rec = (const VocRec*)v->d_rec;
+    V.root_end = v->h.child_start[1];
+    V.word = (const uint32_t*)v->d_word;
+    V.weight = (const double*)v->d_weight;
+    V.n_nodes = v->h.n_nodes();
+    V.L = v->h.L;
+    V.sums = (v->h.weighting == 0 || v->h.weighting == 1) ? 1 : 0;  // TF_IDF, TF (:1145) against IDF, BINARY (:1173)
+    V.norm = v->h.scoring == 5 ? 0 : (v->h.scoring == 1 ? 2 : 1);   // ScoringObject.h:73-90
+    hipLaunchKernelGGL(k_bow_words, dim3((kp_cap + kBowPerBlock - 1) / kBowPerBlock, n), dim3(256), 0, c->stream, V, d_desc,
+                       d_n, kp_cap, v->h.L - levelsup, d_word, d_node, d_weight);
+    int P = 1024;
+    while (P < kp_cap) P <<= 1;
+    const int dual = (size_t)P * 16 <= 128 * 1024 ? 1 : 0;
+    const size_t lds = (size_t)P * (dual ? 16 : 8);
+    if (lds > 64 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bow_vectors), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds));
+    hipLaunchKernelGGL(k_bow_vectors, dim3(n), dim3(1024), lds, c->stream, V, d_n, kp_cap, P, dual, (const uint32_t*)d_word,
+                       (const uint32_t*)d_node, (const double*)d_weight, d_bow_id, d_bow_val, d_bow_n, d_fv_node, d_fv_idx,
+                       d_fv_n);
     HIP_TRY(c, hipGetLastError());
     if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     return ORBX_OK;

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 
 namespace orbx {
@@ -173,6 +174,72 @@ int max_keypoints(const std::vector<LevelGeom>& levels) {
     int n = 0;
     for (const LevelGeom& g : levels) n += g.max_kp;
     return n;
+}
+
+int build_vocabulary(int k, int L, int scoring, int weighting, int n_nodes, const int32_t* parent, const uint8_t* is_leaf,
+                     const uint8_t* desc, const double* weight, VocHost* out) {
+    if (n_nodes < 1 || L < 1 || L > 10 || k < 0 || scoring < 0 || scoring > 5 || weighting < 0 || weighting > 3)
+        return ORBX_E_INVALID;
+    VocHost v;
+    v.k = k;
+    v.L = L;
+    v.scoring = scoring;
+    v.weighting = weighting;
+    std::vector<uint32_t> count((size_t)n_nodes + 1, 0);
+    for (int i = 1; i < n_nodes; ++i) {
+        if (parent[i] < 0 || parent[i] >= i) return ORBX_E_INVALID;
+        ++count[(size_t)parent[i]];
+    }
+    v.child_start.assign((size_t)n_nodes + 1, 0);
+    for (int i = 0; i < n_nodes; ++i) v.child_start[(size_t)i + 1] = v.child_start[(size_t)i] + count[(size_t)i];
+    v.child.assign((size_t)std::max(1, n_nodes - 1), 0);
+    std::vector<uint32_t> cursor(v.child_start.begin(), v.child_start.end() - 1);
+    v.word.assign((size_t)n_nodes, 0);
+    for (int i = 1; i < n_nodes; ++i) {
+        v.child[cursor[(size_t)parent[i]]++] = (uint32_t)i;  // children in node order (:1390-1391)
+        if (is_leaf[i]) v.word[(size_t)i] = (uint32_t)v.n_words++;  // :1408-1415
+    }
+    v.desc.assign(desc, desc + (size_t)n_nodes * 32);
+    v.weight.assign(weight, weight + n_nodes);
+    *out = std::move(v);
+    return ORBX_OK;
+}
+
+int load_vocabulary_text(const char* path, VocHost* out) {
+    std::FILE* f = std::fopen(path, "r");
+    if (!f) return ORBX_E_INVALID;
+    int k = 0, L = 0, n1 = 0, n2 = 0;
+    if (std::fscanf(f, "%d %d %d %d", &k, &L, &n1, &n2) != 4 || k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 || n1 > 5 ||
+        n2 < 0 || n2 > 3) {  // :1359-1363
+        std::fclose(f);
+        return ORBX_E_INVALID;
+    }
+    std::vector<int32_t> parent(1, 0);
+    std::vector<uint8_t> leaf(1, 0), desc(32, 0);
+    std::vector<double> weight(1, 0.0);
+    for (;;) {
+        int pid, is_leaf;
+        if (std::fscanf(f, "%d %d", &pid, &is_leaf) != 2) break;  // end of file (a trailing empty line adds no node here)
+        uint8_t d[32];
+        bool ok = true;
+        for (int i = 0; i < 32 && ok; ++i) {
+            int b;
+            ok = std::fscanf(f, "%d", &b) == 1;
+            d[i] = (uint8_t)b;
+        }
+        double w = 0.0;
+        ok = ok && std::fscanf(f, "%lf", &w) == 1;
+        if (!ok) {
+            std::fclose(f);
+            return ORBX_E_INVALID;
+        }
+        parent.push_back(pid);
+        leaf.push_back(is_leaf > 0);
+        desc.insert(desc.end(), d, d + 32);
+        weight.push_back(w);
+    }
+    std::fclose(f);
+    return build_vocabulary(k, L, n1, n2, (int)parent.size(), parent.data(), leaf.data(), desc.data(), weight.data(), out);
 }
 
 }  // namespace orbx

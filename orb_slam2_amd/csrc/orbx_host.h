@@ -84,5 +84,24 @@ void build_fast_tiles(const std::vector<LevelGeom>& levels, const std::vector<Ce
 void build_resize_taps(int sn, int dn, bool clamp_index, std::vector<ResizeTap>* taps);
 int max_keypoints(const std::vector<LevelGeom>& levels);
 
+// A DBoW2 vocabulary tree flattened for the device (reference
+// Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:296-320, :1338-1425).  Node 0 is the root.
+struct VocHost {
+    int k = 0, L = 0, scoring = 0, weighting = 0;
+    std::vector<uint32_t> child_start, child;  // CSR of the children lists, in node order
+    std::vector<uint8_t> desc;                 // n_nodes x 32
+    std::vector<uint32_t> word;                // word id of the nodes the file flags as leaves, else 0
+    std::vector<double> weight;
+    int n_words = 0;
+    int n_nodes() const { return (int)word.size(); }
+};
+// Builds the tree from per-node arrays (entry 0 = root, its parent / is_leaf are ignored).
+// Returns ORBX_OK or ORBX_E_INVALID (a parent that is not an earlier node, enum values out of range).
+int build_vocabulary(int k, int L, int scoring, int weighting, int n_nodes, const int32_t* parent, const uint8_t* is_leaf,
+                     const uint8_t* desc, const double* weight, VocHost* out);
+// Reads the text format of loadFromTextFile (:1338-1425): header "k L scoring weighting", then one
+// line per node: parent, is-leaf flag, 32 descriptor bytes, weight.
+int load_vocabulary_text(const char* path, VocHost* out);
+
 }  // namespace orbx
 #endif

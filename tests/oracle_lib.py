@@ -90,6 +90,16 @@ def lib():
         L.orc_remap_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_voc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_voc_create.restype = C.c_void_p
+        L.orc_voc_destroy.argtypes = [C.c_void_p]
+        L.orc_voc_destroy.restype = None
+        L.orc_voc_num_words.argtypes = [C.c_void_p]
+        L.orc_voc_transform_feature.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_voc_transform_feature.restype = None
+        L.orc_voc_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_voc_transform.restype = None
         _ = u8p
         _lib = L
     return _lib
@@ -295,3 +305,82 @@ class Oracle:
 
     def level_keypoint_count(self, l):
         return lib().orc_get_num_level_keypoints(self._c, l)
+
+
+class Vocabulary:
+    """A DBoW2 vocabulary tree in the oracle (TemplatedVocabulary, reference
+    Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h).  Arrays are per node, entry 0 = root."""
+
+    def __init__(self, k, L, scoring, weighting, parent, is_leaf, desc, weight):
+        self.parent = np.ascontiguousarray(parent, np.int32)
+        self.is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+        self.desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        self.weight = np.ascontiguousarray(weight, np.float64)
+        n = len(self.parent)
+        assert len(self.is_leaf) == n and len(self.desc) == n and len(self.weight) == n
+        self.k, self.L, self.scoring, self.weighting = k, L, scoring, weighting
+        self._v = lib().orc_voc_create(k, L, scoring, weighting, n, _ptr(self.parent), _ptr(self.is_leaf),
+                                       _ptr(self.desc), _ptr(self.weight))
+        if not self._v:
+            raise ValueError("invalid vocabulary")
+
+    def __del__(self):
+        if getattr(self, "_v", None):
+            lib().orc_voc_destroy(self._v)
+            self._v = None
+
+    @property
+    def n_words(self):
+        return lib().orc_voc_num_words(self._v)
+
+    def transform_feature(self, desc, levelsup):
+        d = np.ascontiguousarray(desc, np.uint8)
+        w, nd, wt = C.c_uint32(0), C.c_uint32(0), C.c_double(0)
+        lib().orc_voc_transform_feature(self._v, _ptr(d), levelsup, C.byref(w), C.byref(nd), C.byref(wt))
+        return w.value, nd.value, wt.value
+
+    def transform(self, descs, levelsup):
+        """(bow_id, bow_val, fv_node, fv_idx) of a frame's descriptors (n x 32)."""
+        d = np.ascontiguousarray(descs, np.uint8).reshape(-1, 32)
+        n = len(d)
+        bid, bval = np.zeros(max(1, n), np.uint32), np.zeros(max(1, n), np.float64)
+        fnode, fidx = np.zeros(max(1, n), np.uint32), np.zeros(max(1, n), np.uint32)
+        nb, nf = C.c_int(0), C.c_int(0)
+        lib().orc_voc_transform(self._v, _ptr(d), n, levelsup, _ptr(bid), _ptr(bval), C.byref(nb), _ptr(fnode),
+                                _ptr(fidx), C.byref(nf))
+        return bid[:nb.value], bval[:nb.value], fnode[:nf.value], fidx[:nf.value]
+
+    def save_text(self, path):
+        """The text format of saveToTextFile / loadFromTextFile (:1338-1460)."""
+        with open(path, "w") as f:
+            f.write("%d %d  %d %d\n" % (self.k, self.L, self.scoring, self.weighting))
+            for i in range(1, len(self.parent)):
+                f.write("%d %d %s %r\n" % (self.parent[i], int(self.is_leaf[i]), " ".join(str(int(b)) for b in self.desc[i]),
+                                            float(self.weight[i])))
+
+
+def random_vocabulary(k, L, seed, scoring=0, weighting=0, prune=0.0, stop=0.0):
+    """A seeded random tree: every node above level L gets k children (a fraction `prune` of the
+    inner nodes below the root gets none and so ends early), centres are random bytes, word weights
+    uniform in (0.5, 8) with a fraction `stop` of them 0 (stopped words).  Nodes are numbered level
+    by level as DBoW2's k-means construction does."""
+    rng = np.random.default_rng(seed)
+    parent, is_leaf, level = [0], [0], [0]
+    frontier = [0]
+    for lev in range(1, L + 1):
+        nxt = []
+        for p in frontier:
+            if p != 0 and lev <= L and rng.random() < prune:
+                continue  # an inner node without children: a leaf by isLeaf() that the file does not flag
+            for _ in range(k):
+                parent.append(p)
+                is_leaf.append(1 if lev == L else 0)
+                level.append(lev)
+                nxt.append(len(parent) - 1)
+        frontier = nxt
+    n = len(parent)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    weight = rng.uniform(0.5, 8.0, n)
+    weight[rng.random(n) < stop] = 0.0
+    weight[0] = 0.0
+    return Vocabulary(k, L, scoring, weighting, parent, is_leaf, desc, weight)
