@@ -29,6 +29,10 @@
  *       coefficients 1868/9617/4899; remap = maps rounded to 1/32 px (round half to even),
  *       15-bit bilinear weights.  Later OpenCV releases changed the gray coefficients.
  *   D9  cv::undistortPoints as in OpenCV 3.4.5: exactly 5 iterations, IEEE double, no contraction.
+ *   D10 bag of words: the vocabulary loader of the reference appends, for a text file ending in a
+ *       newline, one more child of the root whose centre is uninitialised memory; that node is not
+ *       reproduced.  The node id of a feature whose branch ends above level L - levelsup is 0 (the
+ *       reference leaves it unset).  Sums and norms are IEEE double in the reference's order.
  *   D6  a = cos, b = sin of the float32 radian angle are float32 roundings of a
  *       double-precision evaluation (fixed range reduction + fdlibm kernels, explicit
  *       fma) -- the correctly rounded value on every input checked.
