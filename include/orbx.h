@@ -203,6 +203,31 @@ int orbx_bow_transform_batch_device(orbx_ctx* ctx, orbx_voc* voc, int n, const u
                                     double* d_weight, uint32_t* d_bow_id, double* d_bow_val, int32_t* d_bow_n,
                                     uint32_t* d_fv_node, uint32_t* d_fv_idx, int32_t* d_fv_n, int sync);
 
+/* ---- descriptor consumer: best match inside a window ------------------------------------
+ * Replaces Frame::GetFeaturesInArea (reference src/Frame.cc:338-396) together with the candidate
+ * loop of ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) (reference
+ * src/ORBmatcher.cc:1427-1455) for many projected map points per frame at once, on the outputs
+ * of orbx_undistort_grid_batch_device (d_kps_un, d_cell_start, d_cell_idx) and the extractor's
+ * descriptors.  A query is a projected point: window centre (u, v), half-size radius, level
+ * range as GetFeaturesInArea takes it (max_level < 0: no upper limit), the predicted right
+ * coordinate ur, and the map point's descriptor.  d_u_right (mvuRight, may be null): features with
+ * a value > 0 must lie within radius of ur.  d_taken (may be null): non-zero entries are skipped
+ * -- the reference's "mvpMapPoints[i2] && Observations() > 0" as the caller holds it.  The
+ * reference updates that state inside its loop over the map points; here it is an input, so the
+ * caller orders dependent rounds.  Per query: d_best_idx = feature index of the smallest
+ * distance below 256, first in grid order, or -1; d_best_dist = that distance (256 if none). */
+typedef struct orbx_window_query {
+    float u, v, radius;
+    int32_t min_level, max_level;
+    float ur;
+    uint8_t desc[32];
+} orbx_window_query; /* 56 bytes */
+int orbx_search_window_batch_device(orbx_ctx* ctx, int n, const orbx_kp* d_kps_un, int kp_cap,
+                                    const int32_t* d_cell_start, const int32_t* d_cell_idx, const uint8_t* d_desc,
+                                    const float* d_u_right, const uint8_t* d_taken, float min_x, float min_y,
+                                    float inv_w, float inv_h, const orbx_window_query* d_queries, int q_cap,
+                                    const int32_t* d_nq, int32_t* d_best_idx, int32_t* d_best_dist, int sync);
+
 
 /* ---- the stage after the extractor: stereo association ---------------------------------
  * Replaces Frame::ComputeStereoMatches (reference src/Frame.cc:485-659, descriptor distance

@@ -1188,3 +1188,53 @@ extern "C" void orc_voc_transform(const orc_voc* v, const uint8_t* descs, int n,
         }
     *n_fv = nf;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Frame::GetFeaturesInArea (reference src/Frame.cc:338-396) + the best-distance loop of
+// ORBmatcher::SearchByProjection (reference src/ORBmatcher.cc:1427-1455).
+extern "C" int orc_search_window(const float* kps_xy, const int32_t* octave, const uint8_t* desc, const float* u_right,
+                                 const uint8_t* taken, const int32_t* cell_start, const int32_t* cell_idx, float min_x,
+                                 float min_y, float inv_w, float inv_h, float x, float y, float r, int minLevel,
+                                 int maxLevel, float ur, const uint8_t q_desc[32], int* best_dist) {
+    int bestDist = 256, bestIdx2 = -1;
+    *best_dist = bestDist;
+    const int COLS = 64, ROWS = 48;
+    const int nMinCellX = std::max(0, (int)std::floor((x - min_x - r) * inv_w));  // :343
+    if (nMinCellX >= COLS) return -1;
+    const int nMaxCellX = std::min(COLS - 1, (int)std::ceil((x - min_x + r) * inv_w));
+    if (nMaxCellX < 0) return -1;
+    const int nMinCellY = std::max(0, (int)std::floor((y - min_y - r) * inv_h));
+    if (nMinCellY >= ROWS) return -1;
+    const int nMaxCellY = std::min(ROWS - 1, (int)std::ceil((y - min_y + r) * inv_h));
+    if (nMaxCellY < 0) return -1;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);  // :359
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const int c = ix * ROWS + iy;
+            for (int j = cell_start[c]; j < cell_start[c + 1]; j++) {
+                const int i2 = cell_idx[j];
+                if (bCheckLevels) {
+                    if (octave[i2] < minLevel) continue;
+                    if (maxLevel >= 0)
+                        if (octave[i2] > maxLevel) continue;
+                }
+                const float distx = kps_xy[2 * i2] - x;
+                const float disty = kps_xy[2 * i2 + 1] - y;
+                if (!(std::fabs(distx) < r && std::fabs(disty) < r)) continue;  // :389
+                // the candidate loop of SearchByProjection (src/ORBmatcher.cc:1432-1455)
+                if (taken && taken[i2]) continue;
+                if (u_right && u_right[i2] > 0) {
+                    const float er = std::fabs(ur - u_right[i2]);
+                    if (er > r) continue;
+                }
+                const int dist = orc_descriptor_distance(q_desc, desc + (size_t)i2 * 32);
+                if (dist < bestDist) {
+                    bestDist = dist;
+                    bestIdx2 = i2;
+                }
+            }
+        }
+    *best_dist = bestDist;
+    return bestIdx2;
+}
+

@@ -188,6 +188,22 @@ void orc_voc_transform_feature(const orc_voc* v, const uint8_t desc[32], int lev
 void orc_voc_transform(const orc_voc* v, const uint8_t* descs, int n, int levelsup, uint32_t* bow_id,
                        double* bow_val, int* n_bow, uint32_t* fv_node, uint32_t* fv_idx, int* n_fv);
 
+/* ---- descriptor consumer: best match inside a window ------------------------------------- */
+/* Frame::GetFeaturesInArea (reference src/Frame.cc:338-396) followed by the candidate loop of
+   ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) (reference
+   src/ORBmatcher.cc:1427-1455): among the frame's features inside the square window, on the
+   allowed pyramid levels, not `taken` (the reference's test mvpMapPoints[i2] &&
+   Observations() > 0, as the caller sees it at call time) and, when the feature has a right
+   coordinate (u_right[i2] > 0), within `radius` of the predicted one (`ur`), the one at the
+   smallest descriptor distance below 256, the first such in the order the grid lists them.
+   kps_xy: n (x, y) pairs (mvKeysUn), octave: n levels, desc: n x 32, cell_start / cell_idx: the
+   CSR grid of orc_assign_grid.  u_right and taken may be NULL.  Returns the feature index or -1;
+   *best_dist receives the distance (256 when none). */
+int orc_search_window(const float* kps_xy, const int32_t* octave, const uint8_t* desc, const float* u_right,
+                      const uint8_t* taken, const int32_t* cell_start, const int32_t* cell_idx, float min_x,
+                      float min_y, float inv_w, float inv_h, float u, float v, float radius, int min_level,
+                      int max_level, float ur, const uint8_t q_desc[32], int* best_dist);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,7 +49,7 @@ EXPORTS = [
     "orbx_stage_name", "orbx_strerror", "orbx_last_hip_error", "orbx_version",
     "orbx_stereo_match", "orbx_stereo_match_batch_device", "orbx_gray_batch_device", "orbx_remap_batch_device",
     "orbx_undistort_grid_batch_device",
-    "orbx_voc_create", "orbx_voc_load_text", "orbx_voc_destroy", "orbx_voc_info", "orbx_voc_node", "orbx_bow_transform_batch_device",
+    "orbx_voc_create", "orbx_voc_load_text", "orbx_voc_destroy", "orbx_voc_info", "orbx_voc_node", "orbx_bow_transform_batch_device", "orbx_search_window_batch_device",
 ]
 
 _lib = None
@@ -86,6 +86,8 @@ def load_library():
     L.orbx_voc_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.orbx_voc_node.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(C.c_uint32), vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     L.orbx_bow_transform_batch_device.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]
+    L.orbx_search_window_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp, i32, vp, vp,
+                                                  vp, i32]
     L.orbx_gray_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, i32, i32, vp, i32, C.c_size_t, i32]
     L.orbx_remap_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, vp, vp, i32, vp, i32, i32, i32,
                                           C.c_size_t, i32]
@@ -309,6 +311,15 @@ class ORBextractor:
             C.c_void_p(d_node), C.c_void_p(d_weight), C.c_void_p(d_bow_id), C.c_void_p(d_bow_val), C.c_void_p(d_bow_n),
             C.c_void_p(d_fv_node), C.c_void_p(d_fv_idx), C.c_void_p(d_fv_n), int(sync)), self._ctx)
 
+    def search_window_batch_device(self, n, d_kps_un, kp_cap, d_cell_start, d_cell_idx, d_desc, d_u_right, d_taken, min_x,
+                                   min_y, inv_w, inv_h, d_queries, q_cap, d_nq, d_best_idx, d_best_dist, sync=True):
+        """Frame::GetFeaturesInArea + the best-distance loop of ORBmatcher::SearchByProjection for q_cap queries
+        (WINDOW_QUERY_DTYPE records) per frame; d_u_right / d_taken may be 0; see orbx_search_window_batch_device."""
+        _check(self._L.orbx_search_window_batch_device(
+            self._ctx, n, C.c_void_p(d_kps_un), kp_cap, C.c_void_p(d_cell_start), C.c_void_p(d_cell_idx), C.c_void_p(d_desc),
+            C.c_void_p(d_u_right or None), C.c_void_p(d_taken or None), min_x, min_y, inv_w, inv_h, C.c_void_p(d_queries),
+            q_cap, C.c_void_p(d_nq), C.c_void_p(d_best_idx), C.c_void_p(d_best_dist), int(sync)), self._ctx)
+
     # ---- the stage after the extractor: Frame::ComputeStereoMatches (src/Frame.cc:485-659) ----
     def stereo_match(self, right, mb, mbf, img_left=0, img_right=0):
         """Associates image `img_left` of this extractor's last host-memory extraction with image
@@ -368,6 +379,11 @@ class ORBextractor:
         ms = np.zeros(NUM_STAGES, np.float32)
         _check(self._L.orbx_get_stage_ms(self._ctx, _ptr(ms)), self._ctx)
         return {self._L.orbx_stage_name(i).decode(): float(ms[i]) for i in range(NUM_STAGES)}
+
+
+WINDOW_QUERY_DTYPE = np.dtype([("u", np.float32), ("v", np.float32), ("radius", np.float32), ("min_level", np.int32),
+                               ("max_level", np.int32), ("ur", np.float32), ("desc", np.uint8, (32,))])
+assert WINDOW_QUERY_DTYPE.itemsize == 56
 
 
 class ORBVocabulary:

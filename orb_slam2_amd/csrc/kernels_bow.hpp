@@ -225,5 +225,96 @@ __global__ __launch_bounds__(1024) void k_bow_vectors(VocDev V, const int32_t* _
         for (int t = tid; t < n_bow; t += 1024) bow_val[o + t] = __ddiv_rn(bow_val[o + t], norm);
 }
 
+
+// ---- best match inside a window ----------------------------------------------------------------
+// Frame::GetFeaturesInArea (reference src/Frame.cc:338-396) + the candidate loop of
+// ORBmatcher::SearchByProjection (reference src/ORBmatcher.cc:1427-1455) on the undistorted
+// keypoints, the CSR grid and the descriptors of a batch in device memory.
+struct WindowQuery {     // one projected map point
+    float u, v, radius;  // window centre and half-size
+    int32_t min_level, max_level;
+    float ur;            // predicted right coordinate (compared where the feature has one)
+    uint8_t desc[32];    // the map point's descriptor
+};
+static_assert(sizeof(WindowQuery) == 56, "WindowQuery layout");
+
+struct WindowDev {
+    const orbx_kp* kps_un;       // [n][kp_cap]
+    const int32_t* cell_start;   // [n][64 * 48 + 1]
+    const int32_t* cell_idx;     // [n][kp_cap]
+    const uint8_t* desc;         // [n][kp_cap][32]
+    const float* u_right;        // [n][kp_cap] or null
+    const uint8_t* taken;        // [n][kp_cap] or null
+    float min_x, min_y, inv_w, inv_h;
+    int32_t kp_cap, q_cap;
+};
+
+// Sixteen lanes share one query: lane s takes the window's cells s, s + 16, ... in the order
+// GetFeaturesInArea visits them (column by column); the first strict minimum in visiting order
+// is the minimum of (distance, cell order, position in the cell).
+// grid = (ceil(q_cap / 16), frames), block = 256.
+__global__ __launch_bounds__(256) void k_search_window(WindowDev W, const WindowQuery* __restrict__ queries,
+                                                       const int32_t* __restrict__ n_q, int32_t* __restrict__ best_idx,
+                                                       int32_t* __restrict__ best_dist) {
+    const int f = blockIdx.y, sub = threadIdx.x & 15;
+    const int q = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (q >= min(n_q[f], W.q_cap)) return;  // whole groups leave together
+    const WindowQuery* Q = queries + (size_t)f * W.q_cap + q;
+    const float x = Q->u, y = Q->v, r = Q->radius, ur = Q->ur;
+    const int minLevel = Q->min_level, maxLevel = Q->max_level;
+    const uint4 d0 = *reinterpret_cast<const uint4_unaligned*>(Q->desc), d1 = *reinterpret_cast<const uint4_unaligned*>(Q->desc + 16);
+    const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, W.min_x), r), W.inv_w)));  // :343
+    const int nMaxCellX = min(ORBX_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, W.min_x), r), W.inv_w)));
+    const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, W.min_y), r), W.inv_h)));
+    const int nMaxCellY = min(ORBX_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, W.min_y), r), W.inv_h)));
+    uint32_t key = 0xFFFFFFFFu;
+    int mine = -1;
+    if (nMinCellX < ORBX_GRID_COLS && nMaxCellX >= 0 && nMinCellY < ORBX_GRID_ROWS && nMaxCellY >= 0 &&
+        nMinCellX <= nMaxCellX && nMinCellY <= nMaxCellY) {
+        const bool check_levels = minLevel > 0 || maxLevel >= 0;  // :359
+        const int ncy = nMaxCellY - nMinCellY + 1, nc = (nMaxCellX - nMinCellX + 1) * ncy;
+        const orbx_kp* kps = W.kps_un + (size_t)f * W.kp_cap;
+        const int32_t* cs = W.cell_start + (size_t)f * (ORBX_GRID_COLS * ORBX_GRID_ROWS + 1);
+        const int32_t* ci = W.cell_idx + (size_t)f * W.kp_cap;
+        for (int t = sub; t < nc; t += 16) {
+            const int cx = t / ncy, c = (nMinCellX + cx) * ORBX_GRID_ROWS + nMinCellY + (t - cx * ncy);
+            const int j0 = cs[c], j1 = cs[c + 1];
+            for (int j = j0; j < j1; ++j) {
+                const int i2 = ci[j];
+                const orbx_kp kp = kps[i2];
+                if (check_levels) {
+                    if (kp.octave < minLevel) continue;
+                    if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+                }
+                if (!(fabsf(__fsub_rn(kp.x, x)) < r && fabsf(__fsub_rn(kp.y, y)) < r)) continue;  // :389
+                if (W.taken && W.taken[(size_t)f * W.kp_cap + i2]) continue;                      // ORBmatcher.cc:1435-1437
+                if (W.u_right) {
+                    const float urf = W.u_right[(size_t)f * W.kp_cap + i2];
+                    if (urf > 0 && fabsf(__fsub_rn(ur, urf)) > r) continue;  // :1439-1445
+                }
+                const uint4* dp = reinterpret_cast<const uint4*>(W.desc + ((size_t)f * W.kp_cap + i2) * 32);
+                const uint4 a = dp[0], b = dp[1];
+                const uint32_t dist = __popc(d0.x ^ a.x) + __popc(d0.y ^ a.y) + __popc(d0.z ^ a.z) + __popc(d0.w ^ a.w) +
+                                      __popc(d1.x ^ b.x) + __popc(d1.y ^ b.y) + __popc(d1.z ^ b.z) + __popc(d1.w ^ b.w);
+                const uint32_t kc = (dist << 23) | ((uint32_t)t << 11) | (uint32_t)min(j - j0, 2047);
+                if (dist < 256u && kc < key) {  // bestDist starts at 256, strict "<" (:1451)
+                    key = kc;
+                    mine = i2;
+                }
+            }
+        }
+    }
+    uint32_t kmin = key;
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d, 64));
+    const int src = ((int)(threadIdx.x & 63u) & ~15) + (int)((kmin >> 11) & 15u);  // cell order t is handled by lane t % 16
+    const int win = __shfl(mine, src, 64);
+    if (sub == 0) {
+        const size_t o = (size_t)f * W.q_cap + q;
+        best_idx[o] = kmin == 0xFFFFFFFFu ? -1 : win;
+        best_dist[o] = kmin == 0xFFFFFFFFu ? 256 : (int)(kmin >> 23);
+    }
+}
+
 }  // namespace orbx
 #endif

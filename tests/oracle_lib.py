@@ -90,6 +90,9 @@ def lib():
         L.orc_remap_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_search_window.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                        C.c_int, C.c_int, C.c_float, C.c_void_p, C.POINTER(C.c_int)]
         L.orc_voc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_voc_create.restype = C.c_void_p
         L.orc_voc_destroy.argtypes = [C.c_void_p]
@@ -305,6 +308,24 @@ class Oracle:
 
     def level_keypoint_count(self, l):
         return lib().orc_get_num_level_keypoints(self._c, l)
+
+
+def search_window(xy, octave, desc, u_right, taken, cell_start, cell_idx, min_x, min_y, inv_w, inv_h, u, v, radius,
+                  min_level, max_level, ur, q_desc):
+    """Frame::GetFeaturesInArea + the best-distance loop of SearchByProjection; returns (index, distance)."""
+    xy = np.ascontiguousarray(xy, np.float32)
+    octave = np.ascontiguousarray(octave, np.int32)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    cell_start = np.ascontiguousarray(cell_start, np.int32)
+    cell_idx = np.ascontiguousarray(cell_idx, np.int32)
+    q_desc = np.ascontiguousarray(q_desc, np.uint8)
+    ur_a = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    tk_a = None if taken is None else np.ascontiguousarray(taken, np.uint8)
+    d = C.c_int(0)
+    i = lib().orc_search_window(_ptr(xy), _ptr(octave), _ptr(desc), None if ur_a is None else _ptr(ur_a),
+                                None if tk_a is None else _ptr(tk_a), _ptr(cell_start), _ptr(cell_idx), min_x, min_y,
+                                inv_w, inv_h, u, v, radius, min_level, max_level, ur, _ptr(q_desc), C.byref(d))
+    return i, d.value
 
 
 class Vocabulary:
