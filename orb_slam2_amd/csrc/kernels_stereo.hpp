@@ -138,9 +138,9 @@ constexpr int kStereoWin = kStereoWinL + 11 * 32;  // + right strip rows, pitch 
 // A wave works on eight left keypoints at once, eight lanes each (group = lane >> 3), so that the
 // dependent global loads of the eight (keypoint -> bucket bounds -> bucket entries -> descriptors ->
 // matched right keypoint -> windows) overlap instead of queueing behind one another.
-__global__ __launch_bounds__(256) void k_stereo_search(StereoDev S) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_stereo_search(StereoDev S) {
     __shared__ __attribute__((aligned(16))) uint8_t s_win[4][8][kStereoWin];
-    __shared__ uint32_t s_acc[4][8][64];
+    __shared__ uint16_t s_acc[4][8][64];  // window distances: at most 121 * 510 < 2^16
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = blockIdx.y;
     const int grp = lane >> 3, j = lane & 7;
     const int n_l = min(S.n_l[(int64_t)p * S.n_step], S.kp_cap);
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void k_stereo_search(StereoDev S) {
                         acc += (uint32_t)max(t, -t);
                     }
                 }
-                s_acc[wave][q][lane] = acc;
+                s_acc[wave][q][lane] = (uint16_t)acc;
             }
         }
     }
@@ -295,16 +295,16 @@ __global__ __launch_bounds__(256) void k_stereo_search(StereoDev S) {
     float out_u = -1.0f, out_d = -1.0f;
     int out_sad = -1;
     if (refine) {
-        uint32_t* qa = s_acc[wave][grp];
-        const uint32_t t0 = qa[j] + qa[11 + j] + qa[22 + j] + qa[33 + j] + qa[44 + j];  // shift j
+        uint16_t* qa = s_acc[wave][grp];
+        const uint32_t t0 = (uint32_t)qa[j] + qa[11 + j] + qa[22 + j] + qa[33 + j] + qa[44 + j];  // shift j
         uint32_t t1 = 0;                                                               // shift 8 + j
-        if (j < 3) t1 = qa[8 + j] + qa[19 + j] + qa[30 + j] + qa[41 + j] + qa[52 + j];
+        if (j < 3) t1 = (uint32_t)qa[8 + j] + qa[19 + j] + qa[30 + j] + qa[41 + j] + qa[52 + j];
         // first strict minimum over incR = -5..5 (:604) == minimum of (distance, shift)
         uint32_t k2 = (t0 << 8) | (uint32_t)j;
         if (j < 3) k2 = min(k2, (t1 << 8) | (uint32_t)(8 + j));
         __builtin_amdgcn_wave_barrier();  // every partial sum was read
-        qa[j] = t0;
-        if (j < 3) qa[8 + j] = t1;
+        qa[j] = (uint16_t)t0;
+        if (j < 3) qa[8 + j] = (uint16_t)t1;
 #pragma unroll
         for (int d = 4; d >= 1; d >>= 1) k2 = min(k2, (uint32_t)__shfl_xor((int)k2, d, 64));
         __builtin_amdgcn_wave_barrier();
