@@ -379,10 +379,17 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
         const uint64_t m = __ballot(keep);
         if (m) {
             int base = 0;
-            if (lane == 0) base = atomicAdd(&sh->n_kept, __popcll(m));
+            if (lane == 0) {  // a plain LDS add by one lane for the wave
+                uint32_t got;
+                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                             : "=v"(got)
+                             : "v"((uint32_t)(uintptr_t)&sh->n_kept), "v"((uint32_t)__popcll(m))
+                             : "memory");
+                base = (int)got;
+            }
             base = __builtin_amdgcn_readfirstlane(base);
             if (keep) {
-                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 if (pos < k_cap) s_keptl[pos] = (uint16_t)ke;
                 atomicAdd(&sh->kept[c], 1);
             }
