@@ -1238,3 +1238,115 @@ extern "C" int orc_search_window(const float* kps_xy, const int32_t* octave, con
     return bestIdx2;
 }
 
+
+// ORBmatcher::ComputeThreeMaxima (reference src/ORBmatcher.cc:1638-1679) on the bin sizes.
+static void three_maxima(const int* size, int L, int& ind1, int& ind2, int& ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = size[i];
+        if (s > max1) {
+            max3 = max2; max2 = max1; max1 = s;
+            ind3 = ind2; ind2 = ind1; ind1 = i;
+        } else if (s > max2) {
+            max3 = max2; max2 = s;
+            ind3 = ind2; ind2 = i;
+        } else if (s > max3) {
+            max3 = s;
+            ind3 = i;
+        }
+    }
+    if ((float)max2 < 0.1f * (float)max1) {
+        ind2 = -1;
+        ind3 = -1;
+    } else if ((float)max3 < 0.1f * (float)max1) {
+        ind3 = -1;
+    }
+}
+
+// ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) (reference src/ORBmatcher.cc:1365-1507).
+extern "C" int orc_search_by_projection(const float* kps_xy, const int32_t* octave, const float* angle, const uint8_t* desc,
+                                        const float* u_right, const uint8_t* taken0, int n_kp, const int32_t* cell_start,
+                                        const int32_t* cell_idx, const float* scale_factors, const orc_proj_params* P,
+                                        const float Tcw[12], const float Tlw[12], const orc_map_query* q, int nq,
+                                        int32_t* match, int32_t* query_match) {
+    const int HISTO_LENGTH = 30, TH_HIGH = 100;
+    int nmatches = 0;
+    std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+    const float factor = 1.0f / HISTO_LENGTH;  // :1373
+    std::vector<uint8_t> blocked((size_t)std::max(n_kp, 1), 0);
+    for (int i = 0; i < n_kp; i++) {
+        blocked[i] = taken0 ? taken0[i] : 0;
+        match[i] = -1;
+    }
+    // twc = -Rcw.t()*tcw (:1378): cv::gemm with a transposed operand, sums kept in double, scaled by -1
+    float twc[3];
+    for (int k = 0; k < 3; k++) {
+        double s = 0.0;
+        for (int j = 0; j < 3; j++) s += (double)Tcw[4 * j + k] * (double)Tcw[4 * j + 3];
+        twc[k] = (float)(s * -1.0);
+    }
+    // tlc = Rlw*twc + tlw (:1383): cv::gemm's 3x3 float path, products summed left to right in float
+    float tlc[3];
+    for (int r = 0; r < 3; r++) {
+        const float t = Tlw[4 * r] * twc[0] + Tlw[4 * r + 1] * twc[1] + Tlw[4 * r + 2] * twc[2];
+        tlc[r] = t + Tlw[4 * r + 3];
+    }
+    const bool bForward = tlc[2] > P->mb && !P->mono;    // :1385
+    const bool bBackward = -tlc[2] > P->mb && !P->mono;  // :1386
+    for (int i = 0; i < nq; i++) {
+        query_match[i] = -1;
+        if (q[i].flags & 2) continue;  // no map point, or an outlier (:1392-1394)
+        float c3[3];
+        for (int r = 0; r < 3; r++) {  // x3Dc = Rcw*x3Dw + tcw (:1398)
+            const float t = Tcw[4 * r] * q[i].x + Tcw[4 * r + 1] * q[i].y + Tcw[4 * r + 2] * q[i].z;
+            c3[r] = t + Tcw[4 * r + 3];
+        }
+        const float xc = c3[0], yc = c3[1];
+        const float invzc = (float)(1.0 / (double)c3[2]);
+        if (invzc < 0) continue;
+        const float u = P->fx * xc * invzc + P->cx;
+        const float v = P->fy * yc * invzc + P->cy;
+        if (u < P->min_x || u > P->max_x) continue;
+        if (v < P->min_y || v > P->max_y) continue;
+        const int nLastOctave = q[i].octave;
+        const float radius = P->th * scale_factors[nLastOctave];
+        int minLevel, maxLevel;
+        if (bForward) {
+            minLevel = nLastOctave; maxLevel = -1;
+        } else if (bBackward) {
+            minLevel = 0; maxLevel = nLastOctave;
+        } else {
+            minLevel = nLastOctave - 1; maxLevel = nLastOctave + 1;
+        }
+        const float ur = u - P->mbf * invzc;  // :1446
+        int bestDist = 256;
+        const int bestIdx2 = orc_search_window(kps_xy, octave, desc, u_right, blocked.data(), cell_start, cell_idx, P->min_x,
+                                               P->min_y, P->inv_w, P->inv_h, u, v, radius, minLevel, maxLevel, ur, q[i].desc,
+                                               &bestDist);
+        if (bestDist <= TH_HIGH) {
+            match[bestIdx2] = i;
+            query_match[i] = bestIdx2;
+            if (q[i].flags & 1) blocked[bestIdx2] = 1;  // Observations() > 0: later points skip it (:1440-1442)
+            nmatches++;
+            if (P->check_orientation) {
+                float rot = q[i].angle - angle[bestIdx2];
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (P->check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, size[30];
+        for (int i = 0; i < HISTO_LENGTH; i++) size[i] = (int)rotHist[i].size();
+        three_maxima(size, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (size_t j = 0; j < rotHist[i].size(); j++) {
+                    match[rotHist[i][j]] = -1;
+                    nmatches--;
+                }
+    }
+    return nmatches;
+}

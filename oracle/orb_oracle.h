@@ -33,6 +33,13 @@
  *       newline, one more child of the root whose centre is uninitialised memory; that node is not
  *       reproduced.  The node id of a feature whose branch ends above level L - levelsup is 0 (the
  *       reference leaves it unset).  Sums and norms are IEEE double in the reference's order.
+ *   D11 SearchByProjection (src/ORBmatcher.cc:1365-1507): the pose products go through cv::gemm as
+ *       OpenCV 3.4.5 evaluates them -- Rcw*x3Dw+tcw and Rlw*twc+tlw on its 3x3 float path (products
+ *       summed left to right in float32, then the addend), -Rcw.t()*tcw on its general path (sums in
+ *       double, scaled by -1, rounded to float32); the other float32 statements as written, no
+ *       contraction.  A feature that two map points take (possible only when the first has no
+ *       observations) ends with the later one, and is cleared when either entry falls in a rejected
+ *       rotation bin, as the reference's loops leave it.
  *   D6  a = cos, b = sin of the float32 radian angle are float32 roundings of a
  *       double-precision evaluation (fixed range reduction + fdlibm kernels, explicit
  *       fma) -- the correctly rounded value on every input checked.
@@ -203,6 +210,39 @@ int orc_search_window(const float* kps_xy, const int32_t* octave, const uint8_t*
                       const uint8_t* taken, const int32_t* cell_start, const int32_t* cell_idx, float min_x,
                       float min_y, float inv_w, float inv_h, float u, float v, float radius, int min_level,
                       int max_level, float ur, const uint8_t q_desc[32], int* best_dist);
+
+/* ---- descriptor consumer: ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) ---- */
+/* The whole function (reference src/ORBmatcher.cc:1365-1507): every map point of the last frame is
+   projected with the current pose, searched in its window (orc_search_window), and a match at
+   distance <= TH_HIGH (100) is written to the current frame at once, so that later points skip
+   features held by a point with observations; then the rotation histogram (30 bins,
+   ComputeThreeMaxima :1638-1679) clears the matches outside the three largest bins.
+   q[i]: the last frame's feature i -- world position and descriptor of its map point, the octave
+   of mvKeys[i], the angle of mvKeysUn[i]; flags bit 0 = the map point has Observations() > 0,
+   bit 1 = skip (no map point, or mvbOutlier).  angle: the current frame's mvKeysUn angles.
+   taken0 (may be NULL): features that hold a map point with observations before the call.
+   Tcw / Tlw: rows of the 3x4 [R|t] of the current / last frame.  scale_factors: mvScaleFactors.
+   match[n_kp]: per feature the index i of the map point written last, -1 = none or cleared;
+   query_match[nq]: per i the feature it was written to (before the rotation check), or -1.
+   Returns nmatches. */
+typedef struct orc_map_query {
+    float x, y, z;
+    int32_t octave;
+    float angle;
+    int32_t flags;
+    uint8_t desc[32];
+} orc_map_query; /* 56 bytes */
+typedef struct orc_proj_params {
+    float fx, fy, cx, cy, mbf, mb;
+    float min_x, min_y, max_x, max_y, inv_w, inv_h; /* mnMinX, mnMinY, mnMaxX, mnMaxY, mfGridElement{Width,Height}Inv */
+    float th;
+    int32_t mono, check_orientation;
+} orc_proj_params;
+int orc_search_by_projection(const float* kps_xy, const int32_t* octave, const float* angle, const uint8_t* desc,
+                             const float* u_right, const uint8_t* taken0, int n_kp, const int32_t* cell_start,
+                             const int32_t* cell_idx, const float* scale_factors, const orc_proj_params* P,
+                             const float Tcw[12], const float Tlw[12], const orc_map_query* q, int nq,
+                             int32_t* match, int32_t* query_match);
 
 #ifdef __cplusplus
 }

@@ -93,6 +93,7 @@ def lib():
         L.orc_search_window.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                         C.c_int, C.c_int, C.c_float, C.c_void_p, C.POINTER(C.c_int)]
+        L.orc_search_by_projection.argtypes = [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_void_p]
         L.orc_voc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_voc_create.restype = C.c_void_p
         L.orc_voc_destroy.argtypes = [C.c_void_p]
@@ -326,6 +327,38 @@ def search_window(xy, octave, desc, u_right, taken, cell_start, cell_idx, min_x,
                                 None if tk_a is None else _ptr(tk_a), _ptr(cell_start), _ptr(cell_idx), min_x, min_y,
                                 inv_w, inv_h, u, v, radius, min_level, max_level, ur, _ptr(q_desc), C.byref(d))
     return i, d.value
+
+
+MAP_QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("octave", "<i4"), ("angle", "<f4"), ("flags", "<i4"),
+                            ("desc", "u1", (32,))])
+PROJ_PARAMS_DTYPE = np.dtype([(k, "<f4") for k in ("fx", "fy", "cx", "cy", "mbf", "mb", "min_x", "min_y", "max_x", "max_y",
+                                                   "inv_w", "inv_h", "th")] + [("mono", "<i4"), ("check_orientation", "<i4")])
+
+
+def search_by_projection(xy, octave, angle, desc, u_right, taken0, cell_start, cell_idx, scale_factors, params, Tcw, Tlw,
+                         queries):
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) as the reference runs it, one map
+    point after the other; returns (nmatches, match per feature, feature per query)."""
+    xy = np.ascontiguousarray(xy, np.float32)
+    octave = np.ascontiguousarray(octave, np.int32)
+    angle = np.ascontiguousarray(angle, np.float32)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    cell_start = np.ascontiguousarray(cell_start, np.int32)
+    cell_idx = np.ascontiguousarray(cell_idx, np.int32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    P = np.ascontiguousarray(params, PROJ_PARAMS_DTYPE)
+    Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(12)
+    Tlw = np.ascontiguousarray(Tlw, np.float32).reshape(12)
+    q = np.ascontiguousarray(queries, MAP_QUERY_DTYPE)
+    ur_a = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    tk_a = None if taken0 is None else np.ascontiguousarray(taken0, np.uint8)
+    n_kp = len(octave)
+    match = np.full(max(n_kp, 1), -1, np.int32)
+    qmatch = np.full(max(len(q), 1), -1, np.int32)
+    n = lib().orc_search_by_projection(_ptr(xy), _ptr(octave), _ptr(angle), _ptr(desc), None if ur_a is None else _ptr(ur_a),
+                                       None if tk_a is None else _ptr(tk_a), n_kp, _ptr(cell_start), _ptr(cell_idx), _ptr(sf),
+                                       _ptr(P), _ptr(Tcw), _ptr(Tlw), _ptr(q), len(q), _ptr(match), _ptr(qmatch))
+    return n, match[:n_kp], qmatch[:len(q)]
 
 
 class Vocabulary:
