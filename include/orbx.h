@@ -229,6 +229,43 @@ int orbx_search_window_batch_device(orbx_ctx* ctx, int n, const orbx_kp* d_kps_u
                                     const int32_t* d_nq, int32_t* d_best_idx, int32_t* d_best_dist, int sync);
 
 
+/* ---- descriptor consumer: ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) ----
+ * Replaces the whole function (reference src/ORBmatcher.cc:1365-1507, ComputeThreeMaxima
+ * :1638-1679) for a batch of (current frame, last frame) pairs: the last frame's map points are
+ * projected with the current pose (:1396-1413), searched in their window on the outputs of
+ * orbx_undistort_grid_batch_device and the extractor's descriptors (:1415-1461), matches at
+ * distance <= 100 are written to the current frame so that later points skip features held by a
+ * point with observations (:1440-1442, :1463-1466), and the rotation histogram clears the matches
+ * outside its three largest bins (:1468-1504).  The result is that of the reference's sequential
+ * loop; the points are searched concurrently in rounds (see k_search_projection).
+ * d_queries[f*q_cap + i], i < d_nq[f]: feature i of the last frame.  d_poses[f*24 ..]: rows of the
+ * 3x4 [R|t] of the current frame (Tcw), then of the last frame (Tlw).  d_taken (may be null):
+ * features that hold a map point with observations before the call.  d_u_right may be null.
+ * Scale factors are the context's (mvScaleFactors).  Outputs: d_match[f*kp_cap + k] = index i of
+ * the map point feature k ends with, -1 = none or cleared by the rotation check;
+ * d_query_match[f*q_cap + i] = the feature point i was written to (before the rotation check),
+ * -1 = none; d_nmatches[f] = the reference's return value. */
+typedef struct orbx_map_query {
+    float x, y, z;     /* MapPoint::GetWorldPos */
+    int32_t octave;    /* LastFrame.mvKeys[i].octave */
+    float angle;       /* LastFrame.mvKeysUn[i].angle */
+    int32_t flags;     /* bit 0: Observations() > 0; bit 1: skip (no map point, or mvbOutlier[i]) */
+    uint8_t desc[32];  /* MapPoint::GetDescriptor */
+} orbx_map_query; /* 56 bytes */
+typedef struct orbx_projection_params {
+    float fx, fy, cx, cy, mbf, mb;                   /* Frame::fx .. mb */
+    float min_x, min_y, max_x, max_y, inv_w, inv_h;  /* mnMinX, mnMinY, mnMaxX, mnMaxY, mfGridElement{Width,Height}Inv */
+    float th;                                        /* window half-size at level 0 */
+    int32_t mono;                                    /* bMono */
+    int32_t check_orientation;                       /* ORBmatcher::mbCheckOrientation */
+} orbx_projection_params;
+int orbx_search_by_projection_batch_device(orbx_ctx* ctx, int n, const orbx_kp* d_kps_un, int kp_cap,
+                                           const int32_t* d_cell_start, const int32_t* d_cell_idx,
+                                           const uint8_t* d_desc, const float* d_u_right, const uint8_t* d_taken,
+                                           const orbx_projection_params* params, const float* d_poses,
+                                           const orbx_map_query* d_queries, int q_cap, const int32_t* d_nq,
+                                           int32_t* d_match, int32_t* d_query_match, int32_t* d_nmatches, int sync);
+
 /* ---- the stage after the extractor: stereo association ---------------------------------
  * Replaces Frame::ComputeStereoMatches (reference src/Frame.cc:485-659, descriptor distance
  * src/ORBmatcher.cc:1684-1700): for every left keypoint the best right keypoint in its row

@@ -251,18 +251,14 @@ struct WindowDev {
 
 // Sixteen lanes share one query: lane s takes the window's cells s, s + 16, ... in the order
 // GetFeaturesInArea visits them (column by column); the first strict minimum in visiting order
-// is the minimum of (distance, cell order, position in the cell).
-// grid = (ceil(q_cap / 16), frames), block = 256.
-__global__ __launch_bounds__(256) void k_search_window(WindowDev W, const WindowQuery* __restrict__ queries,
-                                                       const int32_t* __restrict__ n_q, int32_t* __restrict__ best_idx,
-                                                       int32_t* __restrict__ best_dist) {
-    const int f = blockIdx.y, sub = threadIdx.x & 15;
-    const int q = blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (q >= min(n_q[f], W.q_cap)) return;  // whole groups leave together
-    const WindowQuery* Q = queries + (size_t)f * W.q_cap + q;
-    const float x = Q->u, y = Q->v, r = Q->radius, ur = Q->ur;
-    const int minLevel = Q->min_level, maxLevel = Q->max_level;
-    const uint4 d0 = *reinterpret_cast<const uint4_unaligned*>(Q->desc), d1 = *reinterpret_cast<const uint4_unaligned*>(Q->desc + 16);
+// is the minimum of (distance, cell order, position in the cell).  All sixteen lanes of a group
+// call this together; each receives the winner (-1: none) and its key (distance in bits 23..31,
+// 0xFFFFFFFF: none).  held(i2) tells whether feature i2 holds a map point the query must respect;
+// on_cand(i2, dist, key) runs for every candidate that passes the filters.
+template <class Held, class OnCand>
+__device__ __forceinline__ void window_best(const WindowDev& W, int f, float x, float y, float r, float ur, int minLevel,
+                                            int maxLevel, const uint4& d0, const uint4& d1, int sub, Held held,
+                                            OnCand on_cand, int* win_out, uint32_t* key_out) {
     const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, W.min_x), r), W.inv_w)));  // :343
     const int nMaxCellX = min(ORBX_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, W.min_x), r), W.inv_w)));
     const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, W.min_y), r), W.inv_h)));
@@ -287,17 +283,18 @@ __global__ __launch_bounds__(256) void k_search_window(WindowDev W, const Window
                     if (maxLevel >= 0 && kp.octave > maxLevel) continue;
                 }
                 if (!(fabsf(__fsub_rn(kp.x, x)) < r && fabsf(__fsub_rn(kp.y, y)) < r)) continue;  // :389
-                if (W.taken && W.taken[(size_t)f * W.kp_cap + i2]) continue;                      // ORBmatcher.cc:1435-1437
+                if (held(i2)) continue;                                                           // ORBmatcher.cc:1440-1442
                 if (W.u_right) {
                     const float urf = W.u_right[(size_t)f * W.kp_cap + i2];
-                    if (urf > 0 && fabsf(__fsub_rn(ur, urf)) > r) continue;  // :1439-1445
+                    if (urf > 0 && fabsf(__fsub_rn(ur, urf)) > r) continue;  // :1444-1450
                 }
                 const uint4* dp = reinterpret_cast<const uint4*>(W.desc + ((size_t)f * W.kp_cap + i2) * 32);
                 const uint4 a = dp[0], b = dp[1];
                 const uint32_t dist = __popc(d0.x ^ a.x) + __popc(d0.y ^ a.y) + __popc(d0.z ^ a.z) + __popc(d0.w ^ a.w) +
                                       __popc(d1.x ^ b.x) + __popc(d1.y ^ b.y) + __popc(d1.z ^ b.z) + __popc(d1.w ^ b.w);
                 const uint32_t kc = (dist << 23) | ((uint32_t)t << 11) | (uint32_t)min(j - j0, 2047);
-                if (dist < 256u && kc < key) {  // bestDist starts at 256, strict "<" (:1451)
+                on_cand(i2, dist, kc);
+                if (dist < 256u && kc < key) {  // bestDist starts at 256, strict "<" (:1456)
                     key = kc;
                     mine = i2;
                 }
@@ -309,11 +306,277 @@ __global__ __launch_bounds__(256) void k_search_window(WindowDev W, const Window
     for (int d = 8; d >= 1; d >>= 1) kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d, 64));
     const int src = ((int)(threadIdx.x & 63u) & ~15) + (int)((kmin >> 11) & 15u);  // cell order t is handled by lane t % 16
     const int win = __shfl(mine, src, 64);
+    *win_out = kmin == 0xFFFFFFFFu ? -1 : win;
+    *key_out = kmin;
+}
+
+// grid = (ceil(q_cap / 16), frames), block = 256.
+__global__ __launch_bounds__(256) void k_search_window(WindowDev W, const WindowQuery* __restrict__ queries,
+                                                       const int32_t* __restrict__ n_q, int32_t* __restrict__ best_idx,
+                                                       int32_t* __restrict__ best_dist) {
+    const int f = blockIdx.y, sub = threadIdx.x & 15;
+    const int q = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (q >= min(n_q[f], W.q_cap)) return;  // whole groups leave together
+    const WindowQuery* Q = queries + (size_t)f * W.q_cap + q;
+    const uint4 d0 = *reinterpret_cast<const uint4_unaligned*>(Q->desc), d1 = *reinterpret_cast<const uint4_unaligned*>(Q->desc + 16);
+    int win;
+    uint32_t kmin;
+    const uint8_t* taken = W.taken ? W.taken + (size_t)f * W.kp_cap : nullptr;
+    window_best(W, f, Q->u, Q->v, Q->radius, Q->ur, Q->min_level, Q->max_level, d0, d1, sub,
+                [&](int i2) { return taken && taken[i2]; }, [](int, uint32_t, uint32_t) {}, &win, &kmin);
     if (sub == 0) {
         const size_t o = (size_t)f * W.q_cap + q;
-        best_idx[o] = kmin == 0xFFFFFFFFu ? -1 : win;
+        best_idx[o] = win;
         best_dist[o] = kmin == 0xFFFFFFFFu ? 256 : (int)(kmin >> 23);
     }
+}
+
+// ---- ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) as a whole -----------------
+// (reference src/ORBmatcher.cc:1365-1507).  The reference walks the last frame's map points in
+// order and writes each match into the current frame at once, so a later point skips the features
+// that earlier points with observations hold.  Here all undecided points search at the same time,
+// in rounds.  A feature records the index of the point that holds it, and a point respects only
+// holders with a lower index than its own.  A point's choice stands as soon as no undecided
+// earlier point with observations still has that feature among its acceptable candidates
+// (distance <= TH_HIGH) -- then nothing the earlier points can still do changes what this point
+// sees.  The lowest undecided point always qualifies, so the rounds end, with the result of the
+// sequential loop.  Only the first round walks the windows: it leaves each point's acceptable
+// candidates (at most kProjCache, with their preference keys) in scratch memory, and the later
+// rounds -- one thread per undecided point -- pick the best of those not yet held by an earlier
+// point.  A point with more acceptable candidates than the cache holds searches its window again
+// in every round.
+struct MapQuery {        // feature i of the last frame
+    float x, y, z;       // world position of its map point
+    int32_t octave;      // mvKeys[i].octave
+    float angle;         // mvKeysUn[i].angle
+    int32_t flags;       // bit 0: the map point has observations (it holds what it takes); bit 1: skip
+    uint8_t desc[32];    // the map point's descriptor
+};
+static_assert(sizeof(MapQuery) == 56, "MapQuery layout");
+
+struct ProjParams {
+    float fx, fy, cx, cy, mbf, mb;
+    float min_x, min_y, max_x, max_y, inv_w, inv_h;
+    float th;
+    int32_t mono, check_orientation;
+};
+
+struct ProjDev {
+    WindowDev W;             // taken unused
+    ProjParams P;
+    float scale[ORBX_MAX_LEVELS];
+    const float* poses;      // [n][24]: Tcw then Tlw, rows of [R|t]
+    const MapQuery* queries; // [n][q_cap]
+    const int32_t* n_q;      // [n]
+    const uint8_t* taken0;   // [n][kp_cap] or null
+    int32_t* match;          // [n][kp_cap]
+    int32_t* query_match;    // [n][q_cap]
+    int32_t* n_matches;      // [n]
+    int32_t* minq;           // scratch [n][kp_cap]: lowest undecided holder that may still take the feature
+    int32_t* list;           // scratch [n][2][q_cap]: the undecided points of this round / of the next
+    uint2* cache;            // scratch [n][q_cap][kProjCache]: (preference key, feature) of the acceptable candidates
+    int32_t* n_cache;        // scratch [n][q_cap]: how many there are (more than kProjCache: not all are cached)
+    int32_t* held;           // scratch [n][kp_cap]: index of the holding point (-1: before the call, INT_MAX: free)
+};
+
+constexpr int kProjThreads = 1024;
+constexpr int kProjCache = 8;
+constexpr int kHistoLength = 30, kThHigh = 100;  // ORBmatcher.cc:37-39
+
+__device__ __forceinline__ int proj_rot_bin(float last_angle, float cur_angle) {
+    float rot = __fsub_rn(last_angle, cur_angle);  // :1470-1475
+    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+    int bin = (int)roundf(__fmul_rn(rot, 1.0f / kHistoLength));
+    if (bin == kHistoLength) bin = 0;
+    return min(max(bin, 0), kHistoLength - 1);  // angles outside [0, 360) would leave the table in the reference
+}
+
+// grid = frames, block = 1024 (64 groups of sixteen lanes).
+__global__ __launch_bounds__(kProjThreads) void k_search_projection(ProjDev D) {
+    __shared__ float s_T[12];
+    __shared__ int s_dir, s_left, s_nm, s_hist[kHistoLength], s_keep[3], s_cnt[kProjThreads / 16];
+    const int f = blockIdx.x, tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
+    const int kp_cap = D.W.kp_cap, q_cap = D.W.q_cap;
+    const int nq = min(D.n_q[f], q_cap);
+    const MapQuery* Q = D.queries + (size_t)f * q_cap;
+    int32_t* qm = D.query_match + (size_t)f * q_cap;
+    int32_t* match = D.match + (size_t)f * kp_cap;
+    int32_t* minq = D.minq + (size_t)f * kp_cap;
+    int32_t* held = D.held + (size_t)f * kp_cap;
+    uint2* cache = D.cache + (size_t)f * q_cap * kProjCache;
+    int32_t* n_cache = D.n_cache + (size_t)f * q_cap;
+    const ProjParams& P = D.P;
+
+    for (int i = tid; i < kp_cap; i += kProjThreads) {
+        held[i] = (D.taken0 && D.taken0[(size_t)f * kp_cap + i]) ? -1 : 0x7FFFFFFF;
+        match[i] = -1;
+    }
+    for (int q = tid; q < q_cap; q += kProjThreads) qm[q] = -1;
+    if (tid < 12) s_T[tid] = D.poses[(size_t)f * 24 + tid];
+    if (tid < kHistoLength) s_hist[tid] = 0;
+    if (tid < kProjThreads / 16) s_cnt[tid] = 0;
+    if (tid == 0) {
+        const float* Tc = D.poses + (size_t)f * 24;
+        const float* Tl = Tc + 12;
+        // twc = -Rcw.t()*tcw (:1378): sums in double, scaled by -1, rounded to float
+        float twc[3];
+        for (int k = 0; k < 3; ++k) {
+            double s = 0.0;
+            for (int j = 0; j < 3; ++j) s = __dadd_rn(s, __dmul_rn((double)Tc[4 * j + k], (double)Tc[4 * j + 3]));
+            twc[k] = (float)__dmul_rn(s, -1.0);
+        }
+        // tlc.z of tlc = Rlw*twc + tlw (:1383): float products summed left to right, then the addend
+        const float t = __fadd_rn(__fadd_rn(__fmul_rn(Tl[8], twc[0]), __fmul_rn(Tl[9], twc[1])), __fmul_rn(Tl[10], twc[2]));
+        const float tz = __fadd_rn(t, Tl[11]);
+        s_dir = P.mono ? 0 : (tz > P.mb ? 1 : (-tz > P.mb ? 2 : 0));  // 1 forward, 2 backward (:1385-1386)
+        s_nm = 0;
+    }
+    __syncthreads();
+    const int dir = s_dir;
+
+    // The undecided points of a round are a dense list (round 0: all of them), so that the sixteen-lane
+    // groups share the searches of the later, sparser rounds evenly.
+    int n_list = nq;
+    for (int round = 0; round <= nq && n_list > 0; ++round) {  // every round decides at least the lowest undecided point
+        const int32_t* cur = D.list + ((size_t)f * 2 + (round & 1)) * q_cap;
+        int32_t* next = D.list + ((size_t)f * 2 + ((round + 1) & 1)) * q_cap;
+        for (int i = tid; i < kp_cap; i += kProjThreads) minq[i] = 0x7FFFFFFF;
+        if (tid == 0) s_left = 0;
+        __syncthreads();
+        for (int e = grp; e < n_list; e += kProjThreads / 16) {
+            const int q = round == 0 ? e : cur[e];
+            if (round > 0 && n_cache[q] <= kProjCache) continue;  // decided from the cached candidates below
+            const MapQuery* m = Q + q;
+            int choice = -1;
+            if (!(m->flags & 2)) {
+                float c3[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {  // x3Dc = Rcw*x3Dw + tcw (:1398)
+                    const float t = __fadd_rn(__fadd_rn(__fmul_rn(s_T[4 * r], m->x), __fmul_rn(s_T[4 * r + 1], m->y)),
+                                              __fmul_rn(s_T[4 * r + 2], m->z));
+                    c3[r] = __fadd_rn(t, s_T[4 * r + 3]);
+                }
+                const float invzc = (float)__ddiv_rn(1.0, (double)c3[2]);  // :1402
+                const float u = __fadd_rn(__fmul_rn(__fmul_rn(P.fx, c3[0]), invzc), P.cx);
+                const float v = __fadd_rn(__fmul_rn(__fmul_rn(P.fy, c3[1]), invzc), P.cy);
+                if (!(invzc < 0) && !(u < P.min_x || u > P.max_x) && !(v < P.min_y || v > P.max_y)) {
+                    const int oct = min(max(m->octave, 0), ORBX_MAX_LEVELS - 1);
+                    const float radius = __fmul_rn(P.th, D.scale[oct]);  // :1418
+                    const int lo = dir == 1 ? m->octave : (dir == 2 ? 0 : m->octave - 1);
+                    const int hi = dir == 1 ? -1 : (dir == 2 ? m->octave : m->octave + 1);
+                    const float ur = __fsub_rn(u, __fmul_rn(P.mbf, invzc));  // :1446
+                    const uint4 d0 = *reinterpret_cast<const uint4_unaligned*>(m->desc);
+                    const uint4 d1 = *reinterpret_cast<const uint4_unaligned*>(m->desc + 16);
+                    const bool holds = m->flags & 1;
+                    int win;
+                    uint32_t key;
+                    window_best(D.W, f, u, v, radius, ur, lo, hi, d0, d1, sub, [&](int i2) { return held[i2] < q; },
+                                [&](int i2, uint32_t dist, uint32_t kc) {
+                                    if (dist > (uint32_t)kThHigh) return;
+                                    if (holds) atomicMin(&minq[i2], q);
+                                    if (round == 0) {
+                                        const int slot = atomicAdd(&s_cnt[grp], 1);
+                                        if (slot < kProjCache) cache[(size_t)q * kProjCache + slot] = make_uint2(kc, (uint32_t)i2);
+                                    }
+                                },
+                                &win, &key);
+                    if (win >= 0 && (int)(key >> 23) <= kThHigh) choice = win;  // :1463
+                }
+            }
+            if (sub == 0) {
+                qm[q] = choice < 0 ? -1 : -3 - choice;  // <= -3: undecided with a choice
+                if (round == 0) n_cache[q] = atomicExch(&s_cnt[grp], 0);  // after the group's additions, in wave order
+            }
+        }
+        if (round > 0)
+            for (int e = tid; e < n_list; e += kProjThreads) {
+                const int q = cur[e], nc = n_cache[q];
+                if (nc > kProjCache) continue;
+                const bool holds = Q[q].flags & 1;
+                uint32_t best = 0xFFFFFFFFu;
+                int choice = -1;
+                for (int k = 0; k < nc; ++k) {
+                    const uint2 c = cache[(size_t)q * kProjCache + k];
+                    if (held[c.y] < q) continue;
+                    if (holds) atomicMin(&minq[c.y], q);
+                    if (c.x < best) {
+                        best = c.x;
+                        choice = (int)c.y;
+                    }
+                }
+                qm[q] = choice < 0 ? -1 : -3 - choice;
+            }
+        __syncthreads();
+        for (int e = tid; e < n_list; e += kProjThreads) {
+            const int q = round == 0 ? e : cur[e];
+            const int v = qm[q];
+            if (v > -3) continue;
+            const int win = -3 - v;
+            if (__hip_atomic_load(&minq[win], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= q) {
+                qm[q] = win;
+                if (Q[q].flags & 1) held[win] = q;  // the only holder this feature will ever have
+            } else {
+                next[atomicAdd(&s_left, 1)] = q;
+            }
+        }
+        __syncthreads();
+        n_list = s_left;
+        __syncthreads();  // everyone has read s_left before the next round clears it
+    }
+
+    // the feature ends with the point written last: the holder if there is one (nothing follows
+    // it), else the highest index
+    for (int q = tid; q < nq; q += kProjThreads) {
+        const int v = qm[q];
+        if (v < 0) continue;
+        atomicMax(&match[v], (int)(((uint32_t)(Q[q].flags & 1) << 30) | (uint32_t)q));
+        atomicAdd(&s_nm, 1);
+        if (P.check_orientation) atomicAdd(&s_hist[proj_rot_bin(Q[q].angle, D.W.kps_un[(size_t)f * kp_cap + v].angle)], 1);
+    }
+    __syncthreads();
+    if (P.check_orientation) {
+        if (tid == 0) {  // ComputeThreeMaxima (:1638-1679)
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < kHistoLength; ++i) {
+                const int s = s_hist[i];
+                if (s > max1) {
+                    max3 = max2; max2 = max1; max1 = s;
+                    ind3 = ind2; ind2 = ind1; ind1 = i;
+                } else if (s > max2) {
+                    max3 = max2; max2 = s;
+                    ind3 = ind2; ind2 = i;
+                } else if (s > max3) {
+                    max3 = s;
+                    ind3 = i;
+                }
+            }
+            if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
+                ind2 = -1;
+                ind3 = -1;
+            } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
+                ind3 = -1;
+            }
+            s_keep[0] = ind1;
+            s_keep[1] = ind2;
+            s_keep[2] = ind3;
+        }
+        __syncthreads();
+        for (int q = tid; q < nq; q += kProjThreads) {
+            const int v = qm[q];
+            if (v < 0) continue;
+            const int bin = proj_rot_bin(Q[q].angle, D.W.kps_un[(size_t)f * kp_cap + v].angle);
+            if (bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) {  // :1493-1502
+                held[v] = -2;  // who held it no longer matters
+                atomicSub(&s_nm, 1);
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < kp_cap; i += kProjThreads) {
+        const int m = __hip_atomic_load(&match[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        match[i] = (m < 0 || held[i] == -2) ? -1 : (m & 0x3FFFFFFF);
+    }
+    if (tid == 0) D.n_matches[f] = s_nm;
 }
 
 }  // namespace orbx

@@ -104,6 +104,7 @@ struct orbx_ctx {
     int tiles_level0 = 0;  // the first tiles_level0 entries of `tiles` belong to level 0
     // stereo stage scratch (grown on demand)
     DevBuf d_st_rows, d_st_meta, d_st_wmax, d_st_sad, d_st_u, d_st_depth;
+    DevBuf d_proj_minq, d_proj_state, d_proj_list, d_proj_cache, d_proj_ncache;  // scratch of orbx_search_by_projection_batch_device
 
     bool profiling = false;
     hipEvent_t ev[kEvCount];  // timing events, recorded when profiling is on
@@ -815,7 +816,7 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
     DevBuf* bufs[] = {&c->d_cells, &c->d_tiles, &c->d_pat, &c->d_pyr[0], &c->d_pyr[1], &c->d_blur[0], &c->d_blur[1],
                       &c->d_cand, &c->d_ccount, &c->d_dense_pts, &c->d_dense_node, &c->d_lvl_kps[0], &c->d_lvl_kps[1],
                       &c->d_lvl_count[0], &c->d_lvl_count[1], &c->d_out_kps,
-                      &c->d_out_desc, &c->d_out_n, &c->d_stamps, &c->d_st_rows, &c->d_st_meta, &c->d_st_wmax,
+                      &c->d_out_desc, &c->d_out_n, &c->d_stamps, &c->d_proj_minq, &c->d_proj_state, &c->d_proj_list, &c->d_proj_cache, &c->d_proj_ncache, &c->d_st_rows, &c->d_st_meta, &c->d_st_wmax,
                       &c->d_st_sad, &c->d_st_u, &c->d_st_depth};
     for (DevBuf* b : bufs) release(b);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -1180,6 +1181,49 @@ extern "C" int orbx_search_window_batch_device(orbx_ctx* c, int n, const orbx_kp
     WindowDev W = {d_kps_un, d_cell_start, d_cell_idx, d_desc, d_u_right, d_taken, min_x, min_y, inv_w, inv_h, kp_cap, q_cap};
     hipLaunchKernelGGL(k_search_window, dim3((q_cap + 15) / 16, n), dim3(256), 0, c->stream, W,
                        reinterpret_cast<const WindowQuery*>(d_queries), d_nq, d_best_idx, d_best_dist);
+    HIP_TRY(c, hipGetLastError());
+    if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_search_by_projection_batch_device(orbx_ctx* c, int n, const orbx_kp* d_kps_un, int kp_cap,
+                                                      const int32_t* d_cell_start, const int32_t* d_cell_idx,
+                                                      const uint8_t* d_desc, const float* d_u_right, const uint8_t* d_taken,
+                                                      const orbx_projection_params* params, const float* d_poses,
+                                                      const orbx_map_query* d_queries, int q_cap, const int32_t* d_nq,
+                                                      int32_t* d_match, int32_t* d_query_match, int32_t* d_nmatches,
+                                                      int sync) {
+    static_assert(sizeof(orbx_map_query) == sizeof(MapQuery), "query layout");
+    static_assert(sizeof(orbx_projection_params) == sizeof(ProjParams), "parameter layout");
+    if (!c || !d_kps_un || !d_cell_start || !d_cell_idx || !d_desc || !params || !d_poses || !d_queries || !d_nq || !d_match ||
+        !d_query_match || !d_nmatches || n < 1 || kp_cap < 1 || q_cap < 1)
+        return ORBX_E_INVALID;
+    if (q_cap >= (1 << 30)) return ORBX_E_CAPACITY;
+    HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    { int rc_ = ensure(c, &c->d_proj_minq, (size_t)n * kp_cap * 4); if (rc_) return rc_; }
+    { int rc_ = ensure(c, &c->d_proj_state, (size_t)n * kp_cap * 4); if (rc_) return rc_; }
+    { int rc_ = ensure(c, &c->d_proj_list, (size_t)n * q_cap * 8); if (rc_) return rc_; }
+    { int rc_ = ensure(c, &c->d_proj_cache, (size_t)n * q_cap * kProjCache * 8); if (rc_) return rc_; }
+    { int rc_ = ensure(c, &c->d_proj_ncache, (size_t)n * q_cap * 4); if (rc_) return rc_; }
+    { int rc_ = join(c); if (rc_) return rc_; }
+    ProjDev D;
+    D.W = {d_kps_un, d_cell_start, d_cell_idx, d_desc, d_u_right, nullptr, params->min_x, params->min_y, params->inv_w,
+           params->inv_h, kp_cap, q_cap};
+    std::memcpy(&D.P, params, sizeof(ProjParams));
+    for (int i = 0; i < ORBX_MAX_LEVELS; ++i) D.scale[i] = c->tab.scale[std::min(i, c->prm.nlevels - 1)];
+    D.poses = d_poses;
+    D.queries = reinterpret_cast<const MapQuery*>(d_queries);
+    D.n_q = d_nq;
+    D.taken0 = d_taken;
+    D.match = d_match;
+    D.query_match = d_query_match;
+    D.n_matches = d_nmatches;
+    D.minq = (int32_t*)c->d_proj_minq.p;
+    D.held = (int32_t*)c->d_proj_state.p;
+    D.list = (int32_t*)c->d_proj_list.p;
+    D.cache = (uint2*)c->d_proj_cache.p;
+    D.n_cache = (int32_t*)c->d_proj_ncache.p;
+    hipLaunchKernelGGL(k_search_projection, dim3(n), dim3(kProjThreads), 0, c->stream, D);
     HIP_TRY(c, hipGetLastError());
     if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     return ORBX_OK;
