@@ -376,6 +376,7 @@ struct ProjDev {
     int32_t* list;           // scratch [n][2][q_cap]: the undecided points of this round / of the next
     uint2* cache;            // scratch [n][q_cap][kProjCache]: (preference key, feature) of the acceptable candidates
     int32_t* n_cache;        // scratch [n][q_cap]: how many there are (more than kProjCache: not all are cached)
+    int32_t use_lds;         // minq, held and list live in the workgroup's dynamic LDS (2 * kp_cap + 2 * q_cap ints)
     int32_t* held;           // scratch [n][kp_cap]: index of the holding point (-1: before the call, INT_MAX: free)
 };
 
@@ -401,8 +402,11 @@ __global__ __launch_bounds__(kProjThreads) void k_search_projection(ProjDev D) {
     const MapQuery* Q = D.queries + (size_t)f * q_cap;
     int32_t* qm = D.query_match + (size_t)f * q_cap;
     int32_t* match = D.match + (size_t)f * kp_cap;
-    int32_t* minq = D.minq + (size_t)f * kp_cap;
-    int32_t* held = D.held + (size_t)f * kp_cap;
+    // per-round state: in LDS when the frame's capacities fit, else in global scratch
+    extern __shared__ int32_t s_dyn[];
+    int32_t* minq = D.use_lds ? s_dyn : D.minq + (size_t)f * kp_cap;
+    int32_t* held = D.use_lds ? s_dyn + kp_cap : D.held + (size_t)f * kp_cap;
+    int32_t* lists = D.use_lds ? s_dyn + 2 * kp_cap : D.list + (size_t)f * 2 * q_cap;
     uint2* cache = D.cache + (size_t)f * q_cap * kProjCache;
     int32_t* n_cache = D.n_cache + (size_t)f * q_cap;
     const ProjParams& P = D.P;
@@ -438,8 +442,8 @@ __global__ __launch_bounds__(kProjThreads) void k_search_projection(ProjDev D) {
     // groups share the searches of the later, sparser rounds evenly.
     int n_list = nq;
     for (int round = 0; round <= nq && n_list > 0; ++round) {  // every round decides at least the lowest undecided point
-        const int32_t* cur = D.list + ((size_t)f * 2 + (round & 1)) * q_cap;
-        int32_t* next = D.list + ((size_t)f * 2 + ((round + 1) & 1)) * q_cap;
+        const int32_t* cur = lists + (size_t)(round & 1) * q_cap;
+        int32_t* next = lists + (size_t)((round + 1) & 1) * q_cap;
         for (int i = tid; i < kp_cap; i += kProjThreads) minq[i] = 0x7FFFFFFF;
         if (tid == 0) s_left = 0;
         __syncthreads();

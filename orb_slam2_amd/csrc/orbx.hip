@@ -1223,7 +1223,9 @@ extern "C" int orbx_search_by_projection_batch_device(orbx_ctx* c, int n, const 
     D.list = (int32_t*)c->d_proj_list.p;
     D.cache = (uint2*)c->d_proj_cache.p;
     D.n_cache = (int32_t*)c->d_proj_ncache.p;
-    hipLaunchKernelGGL(k_search_projection, dim3(n), dim3(kProjThreads), 0, c->stream, D);
+    const size_t lds = ((size_t)2 * kp_cap + (size_t)2 * q_cap) * 4;
+    D.use_lds = lds <= 64 * 1024 ? 1 : 0;  // two workgroups per CU keep their round state in LDS
+    hipLaunchKernelGGL(k_search_projection, dim3(n), dim3(kProjThreads), D.use_lds ? lds : 0, c->stream, D);
     HIP_TRY(c, hipGetLastError());
     if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     return ORBX_OK;
