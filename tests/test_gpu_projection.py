@@ -254,8 +254,11 @@ def test_projection_known_answers_on_device(oracle):
         dict(feat([(100, 100), (103, 100)], desc0=[0, 1]), queries=Q(at(101, 100)), u_right=np.array([50.0, -1.0], np.float32)),
         dict(feat([(100, 100), (103, 100)], desc0=[0, 1]), queries=Q(at(101, 100)), u_right=np.array([106.0, -1.0], np.float32)),
     ]
+    frames.append(dict(feat(two), queries=np.zeros(0, oa.MAP_QUERY_DTYPE)))                    # a last frame without map points
+    frames.append(dict(feat([(100, 100)]), queries=Q(at(100, 100, flags=2), at(100, 100, flags=3))))  # only skipped entries
     out = _run_handmade(oracle, frames, _params(10.0, 0))
-    assert [list(e[2]) for e in out] == [[0, 1], [0, 0], [-1, 1], [-1, -1], [3], [4], [1], [1], [0]]
+    assert [list(e[2]) for e in out] == [[0, 1], [0, 0], [-1, 1], [-1, -1], [3], [4], [1], [1], [0], [], [-1, -1]]
+    assert out[9][0] == 0 and out[10][0] == 0
     assert list(out[1][1]) == [1, -1] and [e[0] for e in out[:4]] == [2, 2, 1, 0]
     pts = [(40 + 40 * i, 100) for i in range(14)]
     rot = dict(feat(pts, angles=[0.0] * 12 + [260.0, 10.0]), queries=Q(*[at(40 + 40 * i, 100) for i in range(14)]))
