@@ -140,6 +140,58 @@ def cpu_baseline(base_frames, budget_s=12.0):
     return out
 
 
+def projection_stage(torch, oa, ex, n, cap, d_kps, d_desc, d_n, steps):
+    """Times orbx_search_by_projection_batch_device on the batch the extractor just produced."""
+    fx, fy, cx, cy = 718.856, 718.856, 607.1928, 185.2157  # Examples/Stereo/KITTI00-02.yaml (rectified: no distortion)
+    d_un = torch.zeros((n, cap, 28), dtype=torch.uint8, device="cuda")
+    d_cs = torch.zeros((n, 64 * 48 + 1), dtype=torch.int32, device="cuda")
+    d_ci = torch.zeros((n, cap), dtype=torch.int32, device="cuda")
+    inv_w, inv_h = float(np.float32(64) / np.float32(W)), float(np.float32(48) / np.float32(H))
+    ex.undistort_grid_batch_device(n, d_kps.data_ptr(), cap, d_n.data_ptr(), np.array([fx, fy, cx, cy], np.float32),
+                                   np.zeros(5, np.float32), 0.0, 0.0, inv_w, inv_h, d_un.data_ptr(), d_cs.data_ptr(),
+                                   d_ci.data_ptr(), sync=True)
+    kp = d_un.view(torch.float32)                      # x, y, size, angle, response, octave, class_id
+    g = torch.Generator(device="cuda").manual_seed(7)
+    z = 4.0 + 36.0 * torch.rand((n, cap), device="cuda", generator=g)
+    q = torch.zeros((n, cap, 14), dtype=torch.float32, device="cuda")   # 56-byte orbx_map_query records
+    q[..., 0] = (kp[..., 0] - cx) * z / fx
+    q[..., 1] = (kp[..., 1] - cy) * z / fy
+    q[..., 2] = z
+    q[..., 4] = kp[..., 3]
+    qi = q.view(torch.int32)
+    qi[..., 3] = d_un.view(torch.int32)[..., 5]
+    qi[..., 5] = 1                                      # every map point has observations
+    q.view(torch.uint8)[..., 24:56] = d_desc
+    poses = torch.zeros((n, 24), dtype=torch.float32, device="cuda")
+    poses[:, [0, 5, 10, 12, 17, 22]] = 1.0
+    poses[:, 3] = 0.02 * torch.randn(n, device="cuda", generator=g)
+    poses[:, 11] = -0.3
+    P = np.zeros((), oa.PROJECTION_PARAMS_DTYPE)
+    P["fx"], P["fy"], P["cx"], P["cy"], P["mbf"], P["mb"] = fx, fy, cx, cy, 386.1448, 386.1448 / fx
+    P["min_x"], P["min_y"], P["max_x"], P["max_y"], P["inv_w"], P["inv_h"] = 0, 0, W, H, inv_w, inv_h
+    P["th"], P["mono"], P["check_orientation"] = 15.0, 0, 1
+    d_match = torch.empty((n, cap), dtype=torch.int32, device="cuda")
+    d_qm = torch.empty((n, cap), dtype=torch.int32, device="cuda")
+    d_nm = torch.empty(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+
+    def run():
+        ex.search_by_projection_batch_device(n, d_un.data_ptr(), cap, d_cs.data_ptr(), d_ci.data_ptr(), d_desc.data_ptr(), 0, 0,
+                                             P, poses.data_ptr(), q.data_ptr(), cap, d_n.data_ptr(), d_match.data_ptr(),
+                                             d_qm.data_ptr(), d_nm.data_ptr(), sync=False)
+    run()
+    ex.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    ex.synchronize()
+    ms = 1000.0 * (time.perf_counter() - t0) / steps
+    return {"name": "ORBmatcher::SearchByProjection(current, last) for every frame of the batch, th 15, rotation check "
+                    "(not part of value)",
+            "ms_per_step": ms, "frames_per_s": n / (ms * 1e-3),
+            "matched_fraction": float(d_nm.sum().item()) / max(1.0, float(d_n.sum().item()))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -244,6 +296,16 @@ def main():
     ex.synchronize()
     stereo_ms = 1000.0 * (time.perf_counter() - ts) / args.steps
 
+    # a descriptor consumer further down the tracking thread, timed on its own (not part of `value`):
+    # ORBmatcher::SearchByProjection between consecutive frames, every frame given its own features back
+    # as the last frame's map points, seen from a pose 30 cm further on
+    proj = None
+    if rank == 0:
+        try:
+            proj = projection_stage(torch, oa, ex, n, cap, d_kps, d_desc, d_n, args.steps)
+        except Exception as e:  # the headline measurement does not depend on this stage
+            proj = {"error": "%s: %s" % (type(e).__name__, e)}
+
     if rank == 0:
         counts = d_n.cpu().numpy()
         kavg = float(counts.mean())
@@ -311,6 +373,7 @@ def main():
             "next_stage": {"name": "stereo association of the batch's pairs (not part of value)",
                            "ms_per_step": stereo_ms, "pairs_per_s": args.pairs / (stereo_ms * 1e-3),
                            "matched_fraction": float((d_u >= 0).float().sum().item() / max(1.0, float(counts[0::2].sum())))},
+            "next_stage_matching": proj,
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(base)
