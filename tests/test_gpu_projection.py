@@ -264,3 +264,18 @@ def test_projection_known_answers_on_device(oracle):
     rot = dict(feat(pts, angles=[0.0] * 12 + [260.0, 10.0]), queries=Q(*[at(40 + 40 * i, 100) for i in range(14)]))
     out = _run_handmade(oracle, [rot], _params(10.0, 1))
     assert out[0][0] == 12 and list(out[0][1]) == list(range(12)) + [-1, -1]
+
+
+def test_projection_rejects_bad_arguments():
+    ex = oa.ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=1, keep_pyramid=False)
+    buf = DeviceArray((4096,), np.int32, fill_byte=0)
+    P = _params(10.0, 1)
+    good = dict(n=1, d_kps_un=buf.ptr, kp_cap=8, d_cell_start=buf.ptr, d_cell_idx=buf.ptr, d_desc=buf.ptr, d_u_right=0,
+                d_taken=0, params=P, d_poses=buf.ptr, d_queries=buf.ptr, q_cap=4, d_nq=buf.ptr, d_match=buf.ptr,
+                d_query_match=buf.ptr, d_nmatches=buf.ptr)
+    for bad in (dict(n=0), dict(kp_cap=0), dict(q_cap=0), dict(d_queries=0), dict(d_match=0), dict(d_poses=0),
+                dict(q_cap=1 << 30)):
+        with pytest.raises(oa.OrbxError):
+            ex.search_by_projection_batch_device(**dict(good, **bad))
+    ex.close()
+    buf.free()
