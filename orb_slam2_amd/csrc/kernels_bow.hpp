@@ -438,7 +438,7 @@ __global__ __launch_bounds__(kProjThreads) void k_search_projection(ProjDev D) {
     __syncthreads();
     const int dir = s_dir;
 
-    // The undecided points of a round are a dense list (round 0: all of them), so that the sixteen-lane
+    // The undecided points of a round are a dense list (in the first one: all of them), so that the sixteen-lane
     // groups share the searches of the later, sparser rounds evenly.
     int n_list = nq;
     for (int round = 0; round <= nq && n_list > 0; ++round) {  // every round decides at least the lowest undecided point
