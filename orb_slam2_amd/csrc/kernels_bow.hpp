@@ -249,11 +249,15 @@ struct WindowDev {
     int32_t kp_cap, q_cap;
 };
 
-// Sixteen lanes share one query: lane s takes the window's cells s, s + 16, ... in the order
-// GetFeaturesInArea visits them (column by column); the first strict minimum in visiting order
-// is the minimum of (distance, cell order, position in the cell).  All sixteen lanes of a group
-// call this together; each receives the winner (-1: none) and its key (distance in bits 23..31,
-// 0xFFFFFFFF: none).  held(i2) tells whether feature i2 holds a map point the query must respect;
+// Sixteen lanes share one query.  The grid is stored column by column (cell = column * 48 + row), so
+// the cells a window covers in one grid column are one contiguous run of cell_idx, and the runs of
+// the window's columns, one after the other, are exactly the order in which GetFeaturesInArea
+// visits the features.  The lanes read the runs' bounds (one column per lane, sixteen at a time),
+// number the entries of all runs consecutively and take entries s, s + 16, ... -- every lane has
+// the same amount of work whatever the cells hold.  The first strict minimum in visiting order is
+// the minimum of (distance, entry number).  All sixteen lanes of a group call this together; each
+// receives the winner (-1: none) and its key (distance in bits 23..31, 0xFFFFFFFF: none).
+// held(i2) tells whether feature i2 holds a map point the query must respect;
 // on_cand(i2, dist, key) runs for every candidate that passes the filters.
 template <class Held, class OnCand>
 __device__ __forceinline__ void window_best(const WindowDev& W, int f, float x, float y, float r, float ur, int minLevel,
@@ -265,47 +269,75 @@ __device__ __forceinline__ void window_best(const WindowDev& W, int f, float x, 
     const int nMaxCellY = min(ORBX_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, W.min_y), r), W.inv_h)));
     uint32_t key = 0xFFFFFFFFu;
     int mine = -1;
+    const int lane = (int)(threadIdx.x & 63u), gbase = lane & ~15;
     if (nMinCellX < ORBX_GRID_COLS && nMaxCellX >= 0 && nMinCellY < ORBX_GRID_ROWS && nMaxCellY >= 0 &&
         nMinCellX <= nMaxCellX && nMinCellY <= nMaxCellY) {
         const bool check_levels = minLevel > 0 || maxLevel >= 0;  // :359
-        const int ncy = nMaxCellY - nMinCellY + 1, nc = (nMaxCellX - nMinCellX + 1) * ncy;
+        const int ncx = nMaxCellX - nMinCellX + 1;
         const orbx_kp* kps = W.kps_un + (size_t)f * W.kp_cap;
         const int32_t* cs = W.cell_start + (size_t)f * (ORBX_GRID_COLS * ORBX_GRID_ROWS + 1);
         const int32_t* ci = W.cell_idx + (size_t)f * W.kp_cap;
-        for (int t = sub; t < nc; t += 16) {
-            const int cx = t / ncy, c = (nMinCellX + cx) * ORBX_GRID_ROWS + nMinCellY + (t - cx * ncy);
-            const int j0 = cs[c], j1 = cs[c + 1];
-            for (int j = j0; j < j1; ++j) {
-                const int i2 = ci[j];
-                const orbx_kp kp = kps[i2];
-                if (check_levels) {
-                    if (kp.octave < minLevel) continue;
-                    if (maxLevel >= 0 && kp.octave > maxLevel) continue;
-                }
-                if (!(fabsf(__fsub_rn(kp.x, x)) < r && fabsf(__fsub_rn(kp.y, y)) < r)) continue;  // :389
-                if (held(i2)) continue;                                                           // ORBmatcher.cc:1440-1442
-                if (W.u_right) {
-                    const float urf = W.u_right[(size_t)f * W.kp_cap + i2];
-                    if (urf > 0 && fabsf(__fsub_rn(ur, urf)) > r) continue;  // :1444-1450
-                }
-                const uint4* dp = reinterpret_cast<const uint4*>(W.desc + ((size_t)f * W.kp_cap + i2) * 32);
-                const uint4 a = dp[0], b = dp[1];
-                const uint32_t dist = __popc(d0.x ^ a.x) + __popc(d0.y ^ a.y) + __popc(d0.z ^ a.z) + __popc(d0.w ^ a.w) +
-                                      __popc(d1.x ^ b.x) + __popc(d1.y ^ b.y) + __popc(d1.z ^ b.z) + __popc(d1.w ^ b.w);
-                const uint32_t kc = (dist << 23) | ((uint32_t)t << 11) | (uint32_t)min(j - j0, 2047);
-                on_cand(i2, dist, kc);
-                if (dist < 256u && kc < key) {  // bestDist starts at 256, strict "<" (:1456)
-                    key = kc;
-                    mine = i2;
+        uint32_t order0 = 0;  // entries of the columns handled so far
+        for (int cx0 = 0; cx0 < ncx; cx0 += 16) {
+            // lane s: the run of column cx0 + s
+            int a = 0, len = 0;
+            if (cx0 + sub < ncx) {
+                const int c0 = (nMinCellX + cx0 + sub) * ORBX_GRID_ROWS;
+                a = cs[c0 + nMinCellY];
+                len = cs[c0 + nMaxCellY + 1] - a;
+            }
+            int incl = len;  // inclusive prefix over the group's sixteen lanes
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const int t = __shfl_up(incl, d, 16);
+                if (sub >= d) incl += t;
+            }
+            const int total = __shfl(incl, gbase + 15, 64);
+            const int shift = a - (incl - len);  // entry e of this lane's column is cell_idx[e + shift]
+            // the sixteen lanes stay together through this loop: the shuffles read lanes of the whole group
+            for (int e0 = 0; e0 < total; e0 += 16) {
+                const int e = e0 + sub;
+                // the column of entry e: the first lane whose inclusive prefix exceeds e
+                int k = 0;
+                k += __shfl(incl, gbase + k + 7, 64) <= e ? 8 : 0;
+                k += __shfl(incl, gbase + k + 3, 64) <= e ? 4 : 0;
+                k += __shfl(incl, gbase + k + 1, 64) <= e ? 2 : 0;
+                k += __shfl(incl, gbase + k, 64) <= e ? 1 : 0;
+                const int sh = __shfl(shift, gbase + min(k, 15), 64);
+                if (e < total) {
+                    const int i2 = ci[e + sh];
+                    const orbx_kp kp = kps[i2];
+                    bool ok = !check_levels || (kp.octave >= minLevel && (maxLevel < 0 || kp.octave <= maxLevel));
+                    ok = ok && fabsf(__fsub_rn(kp.x, x)) < r && fabsf(__fsub_rn(kp.y, y)) < r;  // :389
+                    ok = ok && !held(i2);                                                       // ORBmatcher.cc:1440-1442
+                    if (ok && W.u_right) {
+                        const float urf = W.u_right[(size_t)f * W.kp_cap + i2];
+                        if (urf > 0 && fabsf(__fsub_rn(ur, urf)) > r) ok = false;  // :1444-1450
+                    }
+                    if (ok) {
+                        const uint4* dp = reinterpret_cast<const uint4*>(W.desc + ((size_t)f * W.kp_cap + i2) * 32);
+                        const uint4 da = dp[0], db = dp[1];
+                        const uint32_t dist = __popc(d0.x ^ da.x) + __popc(d0.y ^ da.y) + __popc(d0.z ^ da.z) +
+                                              __popc(d0.w ^ da.w) + __popc(d1.x ^ db.x) + __popc(d1.y ^ db.y) +
+                                              __popc(d1.z ^ db.z) + __popc(d1.w ^ db.w);
+                        const uint32_t kc = (dist << 23) | (order0 + (uint32_t)e);
+                        on_cand(i2, dist, kc);
+                        if (dist < 256u && kc < key) {  // bestDist starts at 256, strict "<" (:1456)
+                            key = kc;
+                            mine = i2;
+                        }
+                    }
                 }
             }
+            order0 += (uint32_t)total;
         }
     }
     uint32_t kmin = key;
 #pragma unroll
     for (int d = 8; d >= 1; d >>= 1) kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d, 64));
-    const int src = ((int)(threadIdx.x & 63u) & ~15) + (int)((kmin >> 11) & 15u);  // cell order t is handled by lane t % 16
-    const int win = __shfl(mine, src, 64);
+    // keys are unique (the entry number is), so one lane of the group holds the minimum
+    const uint32_t owners = (uint32_t)(__ballot(key == kmin) >> gbase) & 0xFFFFu;
+    const int win = __shfl(mine, gbase + __ffs((int)owners) - 1, 64);
     *win_out = kmin == 0xFFFFFFFFu ? -1 : win;
     *key_out = kmin;
 }
