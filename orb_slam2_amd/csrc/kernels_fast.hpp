@@ -126,7 +126,8 @@ constexpr int kFastStageDepth = 3;  // 16-byte loads in flight per thread while 
 
 struct FastShared {  // small per-workgroup state in static LDS
     int q_fb;  // survivors queued so far: front end in the low 16 bits, back end in the high 16
-    int n_kept, retry, pad;
+    int n_kept, retry;
+    int n_corner;  // pixels scored as corners in step 2 of the current pass
     int kept[kFastTileCells];
     int th[kFastTileCells];
 };
@@ -135,33 +136,63 @@ struct FastShared {  // small per-workgroup state in static LDS
 // (DARK_RING = true, a "bright" corner) or ring brighter (evaluated as ring - centre).
 template <bool BRIGHT, bool RETRY>
 __device__ __forceinline__ void fast_score_range(const uint8_t* s_tile, uint8_t* s_score, const uint16_t* s_queue,
-                                                 const FastShared* sh, int q_lo, int q_hi, int TP, int SP, int wd, int nc,
-                                                 float inv_wcell, int thr) {
-    for (int q = q_lo + (int)threadIdx.x; q < q_hi; q += 256) {
-        const int e = s_queue[q], u = e & 0xFF, vq = e >> 8;
-        if (u >= wd) continue;  // padding pixels of the last dword of a row
-        const uint8_t* p = s_tile + (vq + 3) * TP + 4 + u;
-        const uint32_t cv2 = (uint32_t)p[0] * 0x00010001u;
-        // ring positions 2j and 2j+1 share a register
-        uint32_t P[8];
-        P[0] = (uint32_t)p[3 * TP] | ((uint32_t)p[3 * TP + 1] << 16);
-        P[1] = (uint32_t)p[2 * TP + 2] | ((uint32_t)p[1 * TP + 3] << 16);
-        P[2] = (uint32_t)p[3] | ((uint32_t)p[-1 * TP + 3] << 16);
-        P[3] = (uint32_t)p[-2 * TP + 2] | ((uint32_t)p[-3 * TP + 1] << 16);
-        P[4] = (uint32_t)p[-3 * TP] | ((uint32_t)p[-3 * TP - 1] << 16);
-        P[5] = (uint32_t)p[-2 * TP - 2] | ((uint32_t)p[-1 * TP - 3] << 16);
-        P[6] = (uint32_t)p[-3] | ((uint32_t)p[1 * TP - 3] << 16);
-        P[7] = (uint32_t)p[2 * TP - 2] | ((uint32_t)p[3 * TP - 1] << 16);
-        uint32_t D[8];
+                                                 FastShared* sh, int q_lo, int q_hi, int TP, int SP, int wd, int nc,
+                                                 float inv_wcell, int thr, uint16_t* s_corner_top, int corner_room) {
+    const int lane = threadIdx.x & 63;
+    for (int q0 = q_lo; q0 < q_hi; q0 += 256) {
+        const int q = q0 + (int)threadIdx.x;
+        bool hit = false;
+        int ke = 0;
+        if (q < q_hi) {
+            const int e = s_queue[q], u = e & 0xFF, vq = e >> 8;
+            if (u < wd) {  // not a padding pixel of the last dword of a row
+                const uint8_t* p = s_tile + (vq + 3) * TP + 4 + u;
+                const uint32_t cv2 = (uint32_t)p[0] * 0x00010001u;
+                // ring positions 2j and 2j+1 share a register
+                uint32_t P[8];
+                P[0] = (uint32_t)p[3 * TP] | ((uint32_t)p[3 * TP + 1] << 16);
+                P[1] = (uint32_t)p[2 * TP + 2] | ((uint32_t)p[1 * TP + 3] << 16);
+                P[2] = (uint32_t)p[3] | ((uint32_t)p[-1 * TP + 3] << 16);
+                P[3] = (uint32_t)p[-2 * TP + 2] | ((uint32_t)p[-3 * TP + 1] << 16);
+                P[4] = (uint32_t)p[-3 * TP] | ((uint32_t)p[-3 * TP - 1] << 16);
+                P[5] = (uint32_t)p[-2 * TP - 2] | ((uint32_t)p[-1 * TP - 3] << 16);
+                P[6] = (uint32_t)p[-3] | ((uint32_t)p[1 * TP - 3] << 16);
+                P[7] = (uint32_t)p[2 * TP - 2] | ((uint32_t)p[3 * TP - 1] << 16);
+                uint32_t D[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const fast_i16x2 a = __builtin_bit_cast(fast_i16x2, cv2), b = __builtin_bit_cast(fast_i16x2, P[j]);
-            D[j] = __builtin_bit_cast(uint32_t, BRIGHT ? a - b : b - a);
+                for (int j = 0; j < 8; ++j) {
+                    const fast_i16x2 a = __builtin_bit_cast(fast_i16x2, cv2), b = __builtin_bit_cast(fast_i16x2, P[j]);
+                    D[j] = __builtin_bit_cast(uint32_t, BRIGHT ? a - b : b - a);
+                }
+                const int S = arc_max_pk(D);
+                if (S > thr) {
+                    const int c = min((int)(((float)u + 0.5f) * inv_wcell), nc - 1);
+                    if (!RETRY || sh->th[c] >= 0) {
+                        s_score[(vq + 1) * SP + 1 + u + c] = (uint8_t)(S - 1);
+                        hit = true;
+                        ke = (c << 14) | e;
+                    }
+                }
+            }
         }
-        const int S = arc_max_pk(D);
-        if (S > thr) {
-            const int c = min((int)(((float)u + 0.5f) * inv_wcell), nc - 1);
-            if (!RETRY || sh->th[c] >= 0) s_score[(vq + 1) * SP + 1 + u + c] = (uint8_t)(S - 1);
+        // the corners are listed (downwards from the top of the survivor list's memory) so that step 3
+        // visits them alone
+        const uint64_t m = __ballot(hit);
+        if (m) {
+            int base = 0;
+            if (lane == 0) {  // a plain LDS add by one lane for the wave
+                uint32_t got;
+                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                             : "=v"(got)
+                             : "v"((uint32_t)(uintptr_t)&sh->n_corner), "v"((uint32_t)__popcll(m))
+                             : "memory");
+                base = (int)got;
+            }
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (hit) {
+                const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (pos < corner_room) s_corner_top[-pos] = (uint16_t)ke;
+            }
         }
     }
 }
@@ -177,7 +208,11 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
 #ifdef ORBX_STAMPS
     t0 = __builtin_amdgcn_s_memtime();
 #endif
-    if (tid == 0) sh->q_fb = 0;
+    if (tid == 0) {
+        sh->q_fb = 0;
+        sh->n_corner = 0;
+    }
+    const int kept_before = sh->n_kept;  // survivors of the first pass (read before anyone adds to it: step 3 is two barriers away)
     __syncthreads();
     // ---- 1. rejection test, four pixels per work item, two pixels per instruction ----
     // Any arc of 9 holds one pixel of each opposite pair, so a corner needs the two compass pairs
@@ -345,11 +380,53 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
         return;
     }
     // ---- 2. full score of the queued pixels ----
-    fast_score_range<true, RETRY>(s_tile, s_score, s_queue, sh, 0, qf, TP, SP, wd, nc, inv_wcell, thr);
-    fast_score_range<false, RETRY>(s_tile, s_score, s_queue, sh, q_cap - qb, q_cap, TP, SP, wd, nc, inv_wcell, thr);
+    const int corner_room = max(0, min(k_cap, k_cap - kept_before));
+    fast_score_range<true, RETRY>(s_tile, s_score, s_queue, sh, 0, qf, TP, SP, wd, nc, inv_wcell, thr, s_keptl + k_cap - 1, corner_room);
+    fast_score_range<false, RETRY>(s_tile, s_score, s_queue, sh, q_cap - qb, q_cap, TP, SP, wd, nc, inv_wcell, thr, s_keptl + k_cap - 1, corner_room);
     __syncthreads();
     ORBX_STAMP(B, stamp_base + 1, t0);
-    // ---- 3. non-max suppression of the queued pixels; survivors are listed and counted per cell ----
+    // ---- 3. non-max suppression; survivors are listed and counted per cell ----
+    // A pixel is a corner on one side at most (two arcs of 9 do not fit a ring of 16), so the corner
+    // list holds no pixel twice.  It is used when it and the survivors it can add both fit beside the
+    // survivors already listed; else step 3 walks the whole queue.
+    const int nco = sh->n_corner;
+    if (kept_before + 2 * nco <= k_cap) {
+        for (int q0 = 0; q0 < nco; q0 += 256) {
+            const int q = q0 + tid;
+            bool keep = false;
+            int ke = 0, c = 0;
+            if (q < nco) {
+                ke = s_keptl[k_cap - 1 - q];
+                c = ke >> 14;
+                const uint8_t* sp = s_score + ((ke >> 8 & 0x3F) + 1) * SP + 1 + (ke & 0xFF) + c;
+                const int sc = sp[0];
+                const int m = max(max(max((int)sp[-1], (int)sp[1]), max((int)sp[-SP - 1], (int)sp[-SP])),
+                                  max(max((int)sp[-SP + 1], (int)sp[SP - 1]), max((int)sp[SP], (int)sp[SP + 1])));
+                keep = sc > m;
+            }
+            const uint64_t m = __ballot(keep);
+            if (m) {
+                int base = 0;
+                if (lane == 0) {  // a plain LDS add by one lane for the wave
+                    uint32_t got;
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=v"(got)
+                                 : "v"((uint32_t)(uintptr_t)&sh->n_kept), "v"((uint32_t)__popcll(m))
+                                 : "memory");
+                    base = (int)got;
+                }
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (keep) {
+                    const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    s_keptl[pos] = (uint16_t)ke;  // below the corner list: pos < kept_before + nco
+                    atomicAdd(&sh->kept[c], 1);
+                }
+            }
+        }
+        __syncthreads();
+        ORBX_STAMP(B, stamp_base + 2, t0);
+        return;
+    }
     const int n_all = qf + qb;
     for (int q0 = 0; q0 < n_all; q0 += 256) {
         const int q = q0 + tid;

@@ -249,6 +249,29 @@ def test_back_to_back_async_batches(oracle):
             a.free()
 
 
+def test_dotted_images(oracle):
+    """Single-pixel dots on a flat ground: few pixels pass the rejection test but most of those are
+    corners, so a tile's corner list runs from nearly empty to over its capacity (step 3 of the FAST
+    kernel then walks the whole queue); stripes of low-contrast dots are only found by the retry at
+    the minimum threshold, in tiles that already hold survivors of the first pass."""
+    w, h = 420, 300
+    ex = oa.ORBextractor(3000, 1.2, 4, 20, 7, max_width=w, max_height=h)
+    orc = oracle.Oracle(3000, 1.2, 4, 20, 7)
+    rng = np.random.default_rng(29)
+    low = (np.arange(w) // 45) % 2 == 1                  # every other 45-pixel stripe: contrast 12
+    for density in (0.02, 0.05, 0.08, 0.12, 0.2):
+        img = np.full((h, w), 100, np.uint8)
+        dots = rng.random((h, w)) < density
+        img[dots] = 200
+        img[dots & low[None, :]] = 112
+        kps, desc = ex(img)
+        okps, odesc = orc.extract(img)
+        _check_stages(ex, orc, img)
+        _check_final(kps, desc, okps, odesc)
+        assert len(kps) > 500
+    ex.close()
+
+
 @pytest.mark.parametrize("w,h,nf,scale,nl,ini,mn,cid", [
     (200, 150, 50, 1.2, 1, 20, 7, 11),        # one level, tiny quota
     (255, 193, 300, 1.5, 3, 20, 7, 12),       # coarse scale factor, odd sizes
