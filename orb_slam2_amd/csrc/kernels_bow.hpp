@@ -531,13 +531,19 @@ __global__ __launch_bounds__(kProjThreads) void k_search_projection(ProjDev D) {
                 const bool holds = Q[q].flags & 1;
                 uint32_t best = 0xFFFFFFFFu;
                 int choice = -1;
-                for (int k = 0; k < nc; ++k) {
-                    const uint2 c = cache[(size_t)q * kProjCache + k];
-                    if (held[c.y] < q) continue;
-                    if (holds) atomicMin(&minq[c.y], q);
-                    if (c.x < best) {
-                        best = c.x;
-                        choice = (int)c.y;
+                // all cached candidates are requested before the first is looked at: one memory round trip
+                uint4 cc[kProjCache / 2];
+                const uint4* cp = reinterpret_cast<const uint4*>(cache + (size_t)q * kProjCache);
+#pragma unroll
+                for (int k = 0; k < kProjCache / 2; ++k) cc[k] = 2 * k < nc ? cp[k] : make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
+#pragma unroll
+                for (int k = 0; k < kProjCache; ++k) {
+                    const uint32_t ckey = (k & 1) ? cc[k / 2].z : cc[k / 2].x, cidx = (k & 1) ? cc[k / 2].w : cc[k / 2].y;
+                    if (k >= nc || held[cidx] < q) continue;
+                    if (holds) atomicMin(&minq[cidx], q);
+                    if (ckey < best) {
+                        best = ckey;
+                        choice = (int)cidx;
                     }
                 }
                 qm[q] = choice < 0 ? -1 : -3 - choice;
