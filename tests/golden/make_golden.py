@@ -41,11 +41,78 @@ def make(name, img, nfeatures, nlevels):
     print(name, img.shape, "K =", len(kps), "cands", ncand)
 
 
+TUM1_K = np.array([517.306408, 516.469215, 318.643040, 255.313989], np.float32)      # Examples/RGB-D/TUM1.yaml
+TUM1_DIST = np.array([0.262383, -0.953104, -0.005358, 0.002628, 1.163314], np.float32)
+TUM1_BF, TUM1_DEPTH_FACTOR = 40.0, 5000.0
+
+
+def frame_of(img, depth):
+    """What Frame::Frame(RGB-D) derives from an image and its depth map (src/Frame.cc:121-176): keypoints,
+    descriptors, undistorted keypoints, the grid, and mvuRight / mvDepth of ComputeStereoFromRGBD (:661-682)."""
+    orc = oracle_lib.Oracle(1000, 1.2, 8, 20, 7)
+    kps, desc = orc.extract(img)
+    xy = np.stack([kps["x"], kps["y"]], 1).astype(np.float32)
+    un = oracle_lib.undistort_points(xy, TUM1_K, TUM1_DIST)
+    h, w = img.shape
+    c = oracle_lib.undistort_points(np.array([[0, 0], [w, 0], [0, h], [w, h]], np.float32), TUM1_K, TUM1_DIST)
+    min_x, max_x = min(c[0, 0], c[2, 0]), max(c[1, 0], c[3, 0])
+    min_y, max_y = min(c[0, 1], c[1, 1]), max(c[2, 1], c[3, 1])
+    inv_w, inv_h = np.float32(64) / np.float32(max_x - min_x), np.float32(48) / np.float32(max_y - min_y)
+    start, idx = oracle_lib.assign_grid(un, min_x, min_y, inv_w, inv_h)
+    d = depth[kps["y"].astype(np.int32), kps["x"].astype(np.int32)].astype(np.float32) / np.float32(TUM1_DEPTH_FACTOR)
+    has = d > 0
+    u_right = np.where(has, un[:, 0] - np.float32(TUM1_BF) / np.where(has, d, 1).astype(np.float32), -1).astype(np.float32)
+    return dict(kps=kps, desc=desc, un=un, start=start, idx=idx, depth=np.where(has, d, -1).astype(np.float32), u_right=u_right,
+                bounds=np.array([min_x, min_y, max_x, max_y, inv_w, inv_h], np.float32),
+                scale=np.array(orc.params.scale[:8], np.float32))
+
+
+def make_projection(name, img0, depth0, img1, depth1):
+    """Two consecutive RGB-D frames of the sequence as (last, current): the last frame's keypoints with a depth
+    become map points (Frame::UnprojectStereo, src/Frame.cc:684-697, world = the last camera), the current
+    frame is searched with the pose of the last one -- Tracking::TrackWithMotionModel before any motion is
+    known (src/Tracking.cc:1029), th = 15 as for RGB-D input."""
+    last, cur = frame_of(img0, depth0), frame_of(img1, depth1)
+    n0 = len(last["kps"])
+    q = np.zeros(n0, oracle_lib.MAP_QUERY_DTYPE)
+    z = last["depth"]
+    ok = z > 0
+    q["x"] = np.where(ok, (last["un"][:, 0] - TUM1_K[2]) * z / TUM1_K[0], 0)
+    q["y"] = np.where(ok, (last["un"][:, 1] - TUM1_K[3]) * z / TUM1_K[1], 0)
+    q["z"] = np.where(ok, z, 1)
+    q["octave"], q["angle"], q["desc"] = last["kps"]["octave"], last["kps"]["angle"], last["desc"]
+    q["flags"] = np.where(ok, 1, 2)
+    P = np.zeros((), oracle_lib.PROJ_PARAMS_DTYPE)
+    P["fx"], P["fy"], P["cx"], P["cy"] = TUM1_K
+    P["mbf"], P["mb"] = TUM1_BF, np.float32(TUM1_BF) / TUM1_K[0]
+    P["min_x"], P["min_y"], P["max_x"], P["max_y"], P["inv_w"], P["inv_h"] = cur["bounds"]
+    P["th"], P["mono"], P["check_orientation"] = 15.0, 0, 1
+    eye = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32)
+    n, match, qmatch = oracle_lib.search_by_projection(cur["un"], cur["kps"]["octave"].astype(np.int32), cur["kps"]["angle"],
+                                                       cur["desc"], cur["u_right"], None, cur["start"], cur["idx"], cur["scale"],
+                                                       P, eye, eye, q)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), image=img1, queries=q.view(np.uint8).reshape(n0, 56),
+                        u_right=cur["u_right"], params=np.frombuffer(P.tobytes(), np.uint8), K=TUM1_K, dist=TUM1_DIST,
+                        nmatches=n, match=match, query_match=qmatch)
+    print(name, "map points", int(ok.sum()), "of", n0, "features", len(cur["kps"]), "nmatches", n)
+
+
 if __name__ == "__main__":
-    make("synth_400x300_f600_l6", synth.make_frame(400, 300, 11, 0), 600, 6)
+    only = sys.argv[1] if len(sys.argv) > 1 else ""   # "extractor" or "projection": regenerate one family only
+    if only in ("", "extractor"):
+        make("synth_400x300_f600_l6", synth.make_frame(400, 300, 11, 0), 600, 6)
     ref_dir = "/root/reference/Examples/Monocular/rgbd_dataset_freiburg1_xyz/rgb"
     if os.path.isdir(ref_dir):
         from PIL import Image
-        f = sorted(os.listdir(ref_dir))[0]
-        gray = np.asarray(Image.open(os.path.join(ref_dir, f)).convert("L"), dtype=np.uint8)
-        make("tum_fr1_xyz_" + f.replace(".png", "").replace(".", "_") + "_f1000_l8", gray, 1000, 8)
+        if only in ("", "extractor"):
+            f = sorted(os.listdir(ref_dir))[0]
+            gray = np.asarray(Image.open(os.path.join(ref_dir, f)).convert("L"), dtype=np.uint8)
+            make("tum_fr1_xyz_" + f.replace(".png", "").replace(".", "_") + "_f1000_l8", gray, 1000, 8)
+        if only not in ("", "projection"):
+            sys.exit(0)
+        # the first two associated (rgb, depth) pairs of Examples/RGB-D/associations/fr1_xyz.txt
+        seq = os.path.dirname(ref_dir)
+        rows = [l.split() for l in open("/root/reference/Examples/RGB-D/associations/fr1_xyz.txt")][:2]
+        g = [np.asarray(Image.open(os.path.join(seq, r[1])).convert("L"), dtype=np.uint8) for r in rows]
+        d = [np.asarray(Image.open(os.path.join(seq, r[3])), dtype=np.uint16) for r in rows]
+        make_projection("projection_tum_fr1_xyz_frames_0_1", g[0], d[0], g[1], d[1])

@@ -9,7 +9,9 @@ import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-FILES = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+ALL = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+FILES = [f for f in ALL if not os.path.basename(f).startswith("projection_")]      # extractor fixtures
+PROJ = [f for f in ALL if os.path.basename(f).startswith("projection_")]           # SearchByProjection fixtures
 
 
 def _sha(a):
@@ -57,3 +59,74 @@ def test_hip_reproduces_golden(path):
         assert len(ex.debug_read(oa.DBG_CANDIDATES, 0, l)) // 12 == g["candidates_per_level"][l]
         assert len(ex.debug_read(oa.DBG_LEVEL_KPS, 0, l)) // 12 == g["keypoints_per_level"][l]
     ex.close()
+
+
+# ---- SearchByProjection between two consecutive real RGB-D frames (tests/golden/projection_*.npz) ----
+def _projection_inputs(g):
+    import oracle_lib
+    P = np.frombuffer(g["params"].tobytes(), oracle_lib.PROJ_PARAMS_DTYPE)[0]
+    q = np.frombuffer(g["queries"].tobytes(), oracle_lib.MAP_QUERY_DTYPE)
+    eye = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32)
+    return P, q, eye
+
+
+def test_projection_fixture_present():
+    assert len(PROJ) >= 1
+
+
+@pytest.mark.parametrize("path", PROJ, ids=[os.path.basename(f) for f in PROJ])
+def test_oracle_reproduces_projection_golden(oracle, path):
+    g = np.load(path, allow_pickle=False)
+    P, q, eye = _projection_inputs(g)
+    orc = oracle.Oracle(1000, 1.2, 8, 20, 7)
+    kps, desc = orc.extract(g["image"])
+    un = oracle.undistort_points(np.stack([kps["x"], kps["y"]], 1).astype(np.float32), g["K"], g["dist"])
+    start, idx = oracle.assign_grid(un, float(P["min_x"]), float(P["min_y"]), float(P["inv_w"]), float(P["inv_h"]))
+    n, match, qm = oracle.search_by_projection(un, kps["octave"].astype(np.int32), kps["angle"], desc, g["u_right"], None, start,
+                                               idx, np.array(orc.params.scale[:8], np.float32), P, eye, eye, q)
+    assert n == int(g["nmatches"]) and n > 400
+    assert np.array_equal(match, g["match"]) and np.array_equal(qm, g["query_match"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", PROJ, ids=[os.path.basename(f) for f in PROJ])
+def test_hip_reproduces_projection_golden(path):
+    """The device chain extract -> undistort + grid -> SearchByProjection on the fixture's current frame."""
+    import orb_slam2_amd as oa
+    from hip_rt import DeviceArray
+    g = np.load(path, allow_pickle=False)
+    P, q, eye = _projection_inputs(g)
+    img = g["image"]
+    h, w = img.shape
+    ex = oa.ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1, keep_pyramid=False)
+    cap = ex.max_keypoints(w, h)
+    q_cap = len(q)
+    d_img = DeviceArray.from_host(img.reshape(1, h, w))
+    d_kps, d_desc = DeviceArray((1, cap, 28), np.uint8, fill_byte=0), DeviceArray((1, cap, 32), np.uint8)
+    d_n = DeviceArray((1,), np.int32, fill_byte=0)
+    d_un = DeviceArray((1, cap, 28), np.uint8, fill_byte=0)
+    d_cs, d_ci = DeviceArray((1, 64 * 48 + 1), np.int32, fill_byte=0), DeviceArray((1, cap), np.int32, fill_byte=0)
+    ur = np.full((1, cap), -1, np.float32)
+    ur[0, :len(g["u_right"])] = g["u_right"]
+    d_ur = DeviceArray.from_host(ur)
+    d_q = DeviceArray.from_host(np.ascontiguousarray(g["queries"]).reshape(1, q_cap * 56))
+    d_nq = DeviceArray.from_host(np.array([q_cap], np.int32))
+    d_poses = DeviceArray.from_host(np.concatenate([eye, eye]).reshape(1, 24))
+    d_match, d_qm = DeviceArray((1, cap), np.int32, fill_byte=0x55), DeviceArray((1, q_cap), np.int32, fill_byte=0x55)
+    d_nm = DeviceArray((1,), np.int32, fill_byte=0x55)
+    ex.extract_batch_device(d_img.ptr, 1, w, h, w, h * w, d_kps.ptr, cap, d_desc.ptr, d_n.ptr, sync=False)
+    ex.undistort_grid_batch_device(1, d_kps.ptr, cap, d_n.ptr, g["K"], g["dist"], float(P["min_x"]), float(P["min_y"]),
+                                   float(P["inv_w"]), float(P["inv_h"]), d_un.ptr, d_cs.ptr, d_ci.ptr, sync=False)
+    Pd = np.zeros((), oa.PROJECTION_PARAMS_DTYPE)
+    for k in Pd.dtype.names:
+        Pd[k] = P[k]
+    ex.search_by_projection_batch_device(1, d_un.ptr, cap, d_cs.ptr, d_ci.ptr, d_desc.ptr, d_ur.ptr, 0, Pd, d_poses.ptr, d_q.ptr,
+                                         q_cap, d_nq.ptr, d_match.ptr, d_qm.ptr, d_nm.ptr, sync=True)
+    k = int(d_n.to_host()[0])
+    assert k == len(g["match"])
+    assert int(d_nm.to_host()[0]) == int(g["nmatches"])
+    assert np.array_equal(d_match.to_host()[0, :k], g["match"])
+    assert np.array_equal(d_qm.to_host()[0], g["query_match"])
+    ex.close()
+    for a in (d_img, d_kps, d_desc, d_n, d_un, d_cs, d_ci, d_ur, d_q, d_nq, d_poses, d_match, d_qm, d_nm):
+        a.free()
