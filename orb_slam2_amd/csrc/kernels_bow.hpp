@@ -420,6 +420,7 @@ struct ProjDev {
 
 constexpr int kProjThreads = 1024;
 constexpr int kProjCache = 8;
+constexpr int kProjLocal = 4;  // list entries per thread whose choice stays in a register between the phases of a round
 constexpr int kHistoLength = 30, kThHigh = 100;  // ORBmatcher.cc:37-39
 
 __device__ __forceinline__ int proj_rot_bin(float last_angle, float cur_angle) {
@@ -428,6 +429,32 @@ __device__ __forceinline__ int proj_rot_bin(float last_angle, float cur_angle) {
     int bin = (int)roundf(__fmul_rn(rot, 1.0f / kHistoLength));
     if (bin == kHistoLength) bin = 0;
     return min(max(bin, 0), kHistoLength - 1);  // angles outside [0, 360) would leave the table in the reference
+}
+
+// The best cached candidate of a listed point that no earlier point holds (-1: none); a holder also
+// marks every such candidate as still wanted by it.
+__device__ __forceinline__ int proj_cached_choice(uint32_t ent, const uint2* cache, const int32_t* n_cache, const int32_t* held,
+                                                  int32_t* minq) {
+    const int q = (int)(ent & 0x3FFFFFFFu), nc = n_cache[q];
+    const bool holds = (ent >> 30) & 1u;
+    uint32_t best = 0xFFFFFFFFu;
+    int choice = -1;
+    // all cached candidates are requested before the first is looked at: one memory round trip
+    uint4 cc[kProjCache / 2];
+    const uint4* cp = reinterpret_cast<const uint4*>(cache + (size_t)q * kProjCache);
+#pragma unroll
+    for (int k = 0; k < kProjCache / 2; ++k) cc[k] = 2 * k < nc ? cp[k] : make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
+#pragma unroll
+    for (int k = 0; k < kProjCache; ++k) {
+        const uint32_t ckey = (k & 1) ? cc[k / 2].z : cc[k / 2].x, cidx = (k & 1) ? cc[k / 2].w : cc[k / 2].y;
+        if (k >= nc || held[cidx] < q) continue;
+        if (holds) atomicMin(&minq[cidx], q);
+        if (ckey < best) {
+            best = ckey;
+            choice = (int)cidx;
+        }
+    }
+    return choice;
 }
 
 // grid = frames, block = 1024 (64 groups of sixteen lanes).
@@ -486,8 +513,9 @@ __global__ __launch_bounds__(kProjThreads) void k_search_projection(ProjDev D) {
         if (tid == 0) s_left = 0;
         __syncthreads();
         for (int e = grp; e < n_list; e += kProjThreads / 16) {
-            const int q = round == 0 ? e : cur[e];
-            if (round > 0 && n_cache[q] <= kProjCache) continue;  // decided from the cached candidates below
+            const uint32_t ent = round == 0 ? (uint32_t)e : (uint32_t)cur[e];
+            if (round > 0 && !(ent >> 31)) continue;  // decided from the cached candidates below
+            const int q = (int)(ent & 0x3FFFFFFFu);
             const MapQuery* m = Q + q;
             int choice = -1;
             if (!(m->flags & 2)) {
@@ -530,41 +558,51 @@ __global__ __launch_bounds__(kProjThreads) void k_search_projection(ProjDev D) {
                 if (round == 0) n_cache[q] = atomicExch(&s_cnt[grp], 0);  // after the group's additions, in wave order
             }
         }
-        if (round > 0)
-            for (int e = tid; e < n_list; e += kProjThreads) {
-                const int q = cur[e], nc = n_cache[q];
-                if (nc > kProjCache) continue;
-                const bool holds = Q[q].flags & 1;
-                uint32_t best = 0xFFFFFFFFu;
-                int choice = -1;
-                // all cached candidates are requested before the first is looked at: one memory round trip
-                uint4 cc[kProjCache / 2];
-                const uint4* cp = reinterpret_cast<const uint4*>(cache + (size_t)q * kProjCache);
+        // later rounds, one thread per undecided point: the best cached candidate that no earlier point holds.
+        // The choice stays in a register until the decision below (the first kProjLocal list entries of a
+        // thread; further ones go through query_match like the searched points).
+        int ch[kProjLocal];
 #pragma unroll
-                for (int k = 0; k < kProjCache / 2; ++k) cc[k] = 2 * k < nc ? cp[k] : make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
+        for (int i = 0; i < kProjLocal; ++i) ch[i] = -1;
+        if (round > 0) {
 #pragma unroll
-                for (int k = 0; k < kProjCache; ++k) {
-                    const uint32_t ckey = (k & 1) ? cc[k / 2].z : cc[k / 2].x, cidx = (k & 1) ? cc[k / 2].w : cc[k / 2].y;
-                    if (k >= nc || held[cidx] < q) continue;
-                    if (holds) atomicMin(&minq[cidx], q);
-                    if (ckey < best) {
-                        best = ckey;
-                        choice = (int)cidx;
-                    }
-                }
-                qm[q] = choice < 0 ? -1 : -3 - choice;
+            for (int i = 0; i < kProjLocal; ++i) {
+                const int e = tid + i * kProjThreads;
+                if (e < n_list && !((uint32_t)cur[e] >> 31)) ch[i] = proj_cached_choice((uint32_t)cur[e], cache, n_cache, held, minq);
             }
+            for (int e = tid + kProjLocal * kProjThreads; e < n_list; e += kProjThreads) {
+                const uint32_t ent = (uint32_t)cur[e];
+                if (ent >> 31) continue;
+                const int c = proj_cached_choice(ent, cache, n_cache, held, minq);
+                qm[ent & 0x3FFFFFFFu] = c < 0 ? -1 : -3 - c;
+            }
+        }
         __syncthreads();
-        for (int e = tid; e < n_list; e += kProjThreads) {
-            const int q = round == 0 ? e : cur[e];
-            const int v = qm[q];
-            if (v > -3) continue;
-            const int win = -3 - v;
+        for (int e = tid, i = 0; e < n_list; e += kProjThreads, ++i) {
+            uint32_t ent;
+            if (round == 0) {  // list entry: point | holds << 30 | "more candidates than the cache holds" << 31
+                ent = (uint32_t)e | ((uint32_t)(Q[e].flags & 1) << 30) | (n_cache[e] > kProjCache ? 0x80000000u : 0u);
+            } else {
+                ent = (uint32_t)cur[e];
+            }
+            const int q = (int)(ent & 0x3FFFFFFFu);
+            int win;
+            if (round > 0 && !(ent >> 31) && i < kProjLocal) {
+                win = i == 0 ? ch[0] : i == 1 ? ch[1] : i == 2 ? ch[2] : ch[3];
+                if (win < 0) {
+                    qm[q] = -1;
+                    continue;
+                }
+            } else {
+                const int v = qm[q];
+                if (v > -3) continue;
+                win = -3 - v;
+            }
             if (__hip_atomic_load(&minq[win], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= q) {
                 qm[q] = win;
-                if (Q[q].flags & 1) held[win] = q;  // the only holder this feature will ever have
+                if ((ent >> 30) & 1u) held[win] = q;  // the only holder this feature will ever have
             } else {
-                next[atomicAdd(&s_left, 1)] = q;
+                next[atomicAdd(&s_left, 1)] = (int32_t)ent;
             }
         }
         __syncthreads();
