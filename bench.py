@@ -106,13 +106,13 @@ def cpu_baseline(base_frames, budget_s=12.0):
     orc.extract(base_frames[0])  # warm-up
     t0 = time.perf_counter()
     done = 0
-    while done < len(base_frames) and (time.perf_counter() - t0) < budget_s:
-        orc.extract(base_frames[done])
+    while (time.perf_counter() - t0) < budget_s * 0.8:   # about 10 s: the generated frames, cycled
+        orc.extract(base_frames[done % len(base_frames)])
         done += 1
     dt = time.perf_counter() - t0
     out = {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-           "sample": "%d of the generated 1241x376 frames, one at a time, single thread, oracle/liborb_oracle.so "
-                     "(g++ -O2)" % done,
+           "sample": "%d extractions over the %d generated 1241x376 frames (cycled), one at a time, single thread, "
+                     "oracle/liborb_oracle.so (g++ -O2)" % (done, len(base_frames)),
            "ms_per_frame": 1000.0 * dt / done}
     # the same oracle, frame-parallel over the host cores this job may use (one instance per thread;
     # the C call releases the interpreter lock)
