@@ -266,7 +266,7 @@ def main():
     # Outside the timed region: the same steps with the stages serialised on one stream, so that each
     # kernel's duration is its own (in the timed region the pyramid and the blur run beside FAST and the
     # quadtree on a second stream and stretch each other).
-    os.environ["ORBX_NO_OVERLAP"] = "1"
+    ex.set_debug_flag(oa.FLAG_NO_OVERLAP, 1)
     serial_sum = {}
     step()
     ex.synchronize()
@@ -275,7 +275,7 @@ def main():
         ex.synchronize()
         for k, v in ex.stage_ms().items():
             serial_sum[k] = serial_sum.get(k, 0.0) + v / min(args.steps, 5)
-    del os.environ["ORBX_NO_OVERLAP"]
+    ex.set_debug_flag(oa.FLAG_NO_OVERLAP, 0)
 
     # the stage after the extractor (stereo association of the pairs of the batch), timed on its own:
     # it is not part of `value`

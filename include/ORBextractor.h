@@ -94,7 +94,8 @@ private:
     void EnsureContext(int width, int height);
 
     orbx_ctx* mpCtx;
-    int mnCtxWidth, mnCtxHeight;
+    int mnCtxWidth, mnCtxHeight;    // size the device context was created for
+    int mnLastWidth, mnLastHeight;  // size of the last image
     int mnDevice;
     bool mbKeepPyramid;
 };

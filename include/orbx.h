@@ -105,7 +105,11 @@ void orbx_destroy(orbx_ctx* ctx);
  * (reference include/ORBextractor.h:59-61, src/ORBextractor.cc:1137-1211); the mask argument
  * of the reference is ignored there and has no counterpart here.
  * kps[kp_cap], desc[kp_cap*32]; *n_out receives the keypoint count.
- * kp_cap must be >= orbx_host_max_keypoints(...) for this image size. */
+ * kp_cap must be >= orbx_host_max_keypoints(...) for this image size.
+ * The call returns when the results are in kps / desc.  Upload, all kernel launches and the
+ * download are captured once per image size into a HIP graph and replayed as one submission
+ * per call (the reference calls the extractor once per image, src/Frame.cc:252, so the cost of
+ * a call is launch overhead as much as kernel time). */
 int orbx_extract(orbx_ctx* ctx, const uint8_t* img, int width, int height, int stride,
                  orbx_kp* kps, int kp_cap, uint8_t* desc, int* n_out);
 
@@ -118,8 +122,20 @@ int orbx_extract_batch(orbx_ctx* ctx, int n, const uint8_t* const* imgs, int wid
 /* As orbx_extract_batch with every buffer already in device memory (HBM-resident input,
  * HBM-resident results).  d_imgs holds n images, image i at d_imgs + i*frame_stride, rows
  * `stride` bytes apart.  d_kps[n*kp_cap], d_desc[n*kp_cap*32], d_n_out[n] are device
- * pointers.  Work is enqueued on the context's stream; if `sync` is non-zero the call
- * returns after the stream has drained, otherwise use orbx_synchronize. */
+ * pointers.  The work is enqueued on streams the context owns (three of them, ordered among
+ * themselves by events; none is exposed).  If `sync` is non-zero the call returns after all of
+ * it has finished.  With sync = 0 it returns at once, and until orbx_synchronize -- or a later
+ * orbx_* call on the same context, each of which orders itself behind this batch -- has
+ * returned:
+ *   - d_imgs must stay valid and unmodified: an input whose pointer, stride and frame stride
+ *     are multiples of 4 is read in place (level 0 of the pyramid is the caller's buffer) by
+ *     the detection, the first pyramid level and the orientation stage, which keep reading
+ *     after the call has returned;
+ *   - d_kps, d_desc and d_n_out must not be read, written or freed: they are written last, by
+ *     the descriptor stage, on a stream of its own.
+ * Work the caller enqueues on streams of its own is not ordered against the batch: synchronise
+ * the context first.  Several batches may be enqueued back to back with sync = 0 (each with its
+ * own output arrays); they run in order and overlap where their stages allow. */
 int orbx_extract_batch_device(orbx_ctx* ctx, int n, const uint8_t* d_imgs, int width, int height,
                               int stride, size_t frame_stride, orbx_kp* d_kps, int kp_cap,
                               uint8_t* d_desc, int32_t* d_n_out, int sync);
@@ -309,6 +325,21 @@ enum {
  * receives the size.  No counterpart in the reference (its intermediates are locals). */
 int orbx_debug_read(orbx_ctx* ctx, int what, int img_idx, int level, void* dst, size_t cap_bytes,
                     size_t* n_bytes);
+
+/* Diagnostic switches.  None changes results; each lets a test or a measurement reach a path
+ * ordinary inputs seldom take.  Their initial values come from the environment, read once in
+ * orbx_create (ORBX_NO_OVERLAP, ORBX_RESIZE_TILES, ORBX_STEREO_BORDER_PATH, ORBX_TRACE,
+ * ORBX_NO_GRAPH: set = 1; ORBX_PIPE_CHUNK=<frames>); this call changes one of them on a live
+ * context after waiting for its work in flight.  No counterpart in the reference. */
+enum {
+    ORBX_FLAG_NO_OVERLAP = 1,         /* all stages on one stream, in stage order                   */
+    ORBX_FLAG_RESIZE_TILES = 2,       /* every pyramid level through the LDS-tiled resize kernel     */
+    ORBX_FLAG_STEREO_BORDER_PATH = 3, /* every stereo window through the reflecting byte loader      */
+    ORBX_FLAG_TRACE = 4,              /* timing prints of the host batch path on stderr              */
+    ORBX_FLAG_NO_GRAPH = 5,           /* orbx_extract issues its launches one by one, no HIP graph   */
+    ORBX_FLAG_PIPE_CHUNK = 6          /* frames per chunk of the pipelined host batch path (0: auto) */
+};
+int orbx_set_debug_flag(orbx_ctx* ctx, int flag, int value);
 
 /* Stage timing with HIP events on the context's stream.  Stages, in order:
  * 0 pyramid, 1 fast, 2 quadtree, 3 blur, 4 orient+describe. */

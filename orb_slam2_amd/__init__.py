@@ -23,6 +23,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 assert KP_DTYPE.itemsize == 28
 
 DBG_BLURRED, DBG_CANDIDATES, DBG_LEVEL_KPS = 1, 2, 3
+FLAG_NO_OVERLAP, FLAG_RESIZE_TILES, FLAG_STEREO_BORDER_PATH, FLAG_TRACE, FLAG_NO_GRAPH, FLAG_PIPE_CHUNK = 1, 2, 3, 4, 5, 6
 
 
 class OrbxError(RuntimeError):
@@ -50,7 +51,7 @@ EXPORTS = [
     "orbx_stereo_match", "orbx_stereo_match_batch_device", "orbx_gray_batch_device", "orbx_remap_batch_device",
     "orbx_undistort_grid_batch_device",
     "orbx_voc_create", "orbx_voc_load_text", "orbx_voc_destroy", "orbx_voc_info", "orbx_voc_node", "orbx_bow_transform_batch_device", "orbx_search_window_batch_device",
-    "orbx_search_by_projection_batch_device",
+    "orbx_search_by_projection_batch_device", "orbx_set_debug_flag",
 ]
 
 _lib = None
@@ -96,6 +97,7 @@ def load_library():
     L.orbx_pyramid_level.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.orbx_debug_read.argtypes = [vp, i32, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.orbx_set_profiling.argtypes = [vp, i32]
+    L.orbx_set_debug_flag.argtypes = [vp, i32, i32]
     L.orbx_get_stage_ms.argtypes = [vp, vp]
     L.orbx_stage_name.argtypes = [i32]
     L.orbx_stage_name.restype = C.c_char_p
@@ -387,6 +389,10 @@ class ORBextractor:
         n = C.c_size_t(0)
         _check(self._L.orbx_debug_read(self._ctx, what, img_idx, level, _ptr(buf), max_bytes, C.byref(n)), self._ctx)
         return buf[:n.value].copy()
+
+    def set_debug_flag(self, flag, value):
+        """One of the FLAG_* diagnostic switches of a live context (see orbx_set_debug_flag)."""
+        _check(self._L.orbx_set_debug_flag(self._ctx, int(flag), int(value)), self._ctx)
 
     def set_profiling(self, on):
         _check(self._L.orbx_set_profiling(self._ctx, int(on)), self._ctx)

@@ -32,7 +32,8 @@ inline int Reflect101(int p, int len) {
 // getters and the device agree bit for bit.
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST),
-      minThFAST(_minThFAST), mpCtx(NULL), mnCtxWidth(0), mnCtxHeight(0), mnDevice(0), mbKeepPyramid(true) {
+      minThFAST(_minThFAST), mpCtx(NULL), mnCtxWidth(0), mnCtxHeight(0), mnLastWidth(0), mnLastHeight(0), mnDevice(0),
+      mbKeepPyramid(true) {
     mvScaleFactor.resize(nlevels);
     mvInvScaleFactor.resize(nlevels);
     mvLevelSigma2.resize(nlevels);
@@ -85,6 +86,8 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
         std::abort();
     }
     EnsureContext(image.cols, image.rows);
+    mnLastWidth = image.cols;
+    mnLastHeight = image.rows;
     const int cap = orbx_host_max_keypoints(nfeatures, (float)scaleFactor, nlevels, image.cols, image.rows);
     if (cap < 0) Fatal("orbx_host_max_keypoints", cap, mpCtx);
     std::vector<orbx_kp> kps(cap);
@@ -167,7 +170,8 @@ void ExtractorNode::DivideNode(ExtractorNode& n1, ExtractorNode& n2, ExtractorNo
 void ORBextractor::ComputeStereoMatches(ORBextractor& right, float mb, float mbf, std::vector<float>& vuRight,
                                         std::vector<float>& vDepth) {
     if (!mpCtx || !right.mpCtx) Fatal("ComputeStereoMatches before operator()", ORBX_E_STATE, mpCtx);
-    const int cap = orbx_host_max_keypoints(nfeatures, (float)scaleFactor, nlevels, mnCtxWidth, mnCtxHeight);
+    // one value per left keypoint: at most what an image of the last size can return
+    const int cap = orbx_host_max_keypoints(nfeatures, (float)scaleFactor, nlevels, mnLastWidth, mnLastHeight);
     if (cap < 0) Fatal("orbx_host_max_keypoints", cap, mpCtx);
     vuRight.assign((size_t)cap, -1.0f);
     vDepth.assign((size_t)cap, -1.0f);

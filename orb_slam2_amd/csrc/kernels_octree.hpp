@@ -220,10 +220,12 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
     for (;;) {
         // ---------------- node step ----------------
         const int n = n_alive;
-        // sort key of an expandable node: size, then list position (earlier first); unique, 0 = not expandable
+        // sort key of an expandable node: size, then list position (earlier first); unique, 0 = not expandable.
+        // The size field holds 16 bits: larger nodes all carry 0xFFFF there and are told apart by their
+        // real counts where the order matters (the ranking of the one-at-a-time phase below).
         for (int i = tid; i < ((n + 3) & ~3); i += 256) {
             const uint32_t c = i < n ? T.cnt[ord[i]] : 0u;
-            T.key[i] = c > 1 ? (c << 16) | (0xFFFFu - (uint32_t)i) : 0u;
+            T.key[i] = c > 1 ? (min(c, 0xFFFFu) << 16) | (0xFFFFu - (uint32_t)i) : 0u;
         }
         if (tid == 0) {
             s_i[0] = 0x7FFFFFFF;
@@ -244,10 +246,21 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
                 const uint32_t ki = T.key[i];
                 if (ki) {
                     int r = 0;
-                    const uint4* k4 = reinterpret_cast<const uint4*>(T.key);
-                    for (int j = 0; j < (n + 3) >> 2; ++j) {
-                        const uint4 kj = k4[j];
-                        r += (kj.x > ki ? 1 : 0) + (kj.y > ki ? 1 : 0) + (kj.z > ki ? 1 : 0) + (kj.w > ki ? 1 : 0);
+                    if ((ki >> 16) != 0xFFFFu) {
+                        const uint4* k4 = reinterpret_cast<const uint4*>(T.key);
+                        for (int j = 0; j < (n + 3) >> 2; ++j) {
+                            const uint4 kj = k4[j];
+                            r += (kj.x > ki ? 1 : 0) + (kj.y > ki ? 1 : 0) + (kj.z > ki ? 1 : 0) + (kj.w > ki ? 1 : 0);
+                        }
+                    } else {
+                        // a node of 65535 points or more: only nodes of that class can precede it, by their
+                        // real sizes, earlier list position first among equals
+                        const uint32_t ci = T.cnt[ord[i]];
+                        for (int j = 0; j < n; ++j) {
+                            if ((T.key[j] >> 16) != 0xFFFFu) continue;
+                            const uint32_t cj = T.cnt[ord[j]];
+                            r += (cj > ci || (cj == ci && j < i)) ? 1 : 0;
+                        }
                     }
                     T.rank[i] = (uint16_t)r;
                     cnt_exp++;

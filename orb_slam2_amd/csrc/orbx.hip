@@ -32,6 +32,11 @@ const int8_t kPattern[1024] = {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Dynamic LDS a launch of the LDS-heavy kernels may ask for: the CU's 160 KB less room for their
+// small static arrays.  The limit is a property of the kernel on a device, shared by every context,
+// so it is set to this one value and never to a context's own need.
+constexpr int kMaxDynamicLds = 160 * 1024 - 256;
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -106,6 +111,16 @@ struct orbx_ctx {
     DevBuf d_st_rows, d_st_meta, d_st_wmax, d_st_sad, d_st_u, d_st_depth;
     DevBuf d_proj_minq, d_proj_state, d_proj_list, d_proj_cache, d_proj_ncache;  // scratch of orbx_search_by_projection_batch_device
 
+    // diagnostic switches: read from the environment once, in orbx_create; orbx_set_debug_flag changes them
+    bool dbg_no_overlap = false, dbg_resize_tiles = false, dbg_stereo_border = false, dbg_trace = false, dbg_no_graph = false;
+    int dbg_pipe_chunk = 0;
+    // launch graph of the single-frame host path (captured once per image size, replayed by orbx_extract)
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_w = -1, graph_h = -1, graph_cap = 0;
+    bool capturing = false;
+    void* h_gin = nullptr;   // pinned: the frame at device pitch (source of the graph's upload node)
+    void* h_gout = nullptr;  // pinned: [cap keypoints][cap descriptors][count] (target of its download nodes)
+
     bool profiling = false;
     hipEvent_t ev[kEvCount];  // timing events, recorded when profiling is on
     bool ev_made = false;
@@ -146,10 +161,21 @@ int sync_ctx(orbx_ctx* c) {
     return ORBX_OK;
 }
 
+// Forgets the captured single-frame launch graph (see build_graph) and its pinned buffers.
+void drop_graph(orbx_ctx* c) {
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    c->graph_exec = nullptr;
+    c->graph_w = c->graph_h = -1;
+    if (c->h_gin) (void)hipHostFree(c->h_gin);
+    if (c->h_gout) (void)hipHostFree(c->h_gout);
+    c->h_gin = c->h_gout = nullptr;
+}
+
 int ensure(orbx_ctx* c, DevBuf* b, size_t bytes) {
     if (bytes <= b->bytes) return ORBX_OK;
     if (b->p) {
         { int rc_ = sync_ctx(c); if (rc_) return rc_; }
+        drop_graph(c);  // the graph's nodes may hold this buffer's address
         HIP_TRY(c, hipFree(b->p));
         b->p = nullptr;
         b->bytes = 0;
@@ -169,6 +195,12 @@ void release(DevBuf* b) {
 // Rebuilds every size-dependent table for a w x h input and uploads it.
 int set_geometry(orbx_ctx* c, int w, int h) {
     if (w == c->cur_w && h == c->cur_h) return ORBX_OK;
+    // Until the last table has been uploaded the context describes no size: a failure on the way
+    // leaves device tables that match neither the old nor the new geometry, so the next call must
+    // rebuild them all, and nothing may read the last batch through the old level table.
+    c->cur_w = c->cur_h = -1;
+    c->have_last = false;
+    drop_graph(c);  // its kernel arguments describe the old size
     std::vector<LevelGeom> levels;
     std::vector<CellDesc> cells;
     int rc = build_level_geometry(c->tab, w, h, &levels, &cells);
@@ -185,6 +217,7 @@ int set_geometry(orbx_ctx* c, int w, int h) {
     if (oct_lds > 160 * 1024 - 256) return ORBX_E_GEOMETRY;
     for (LevelGeom& g : levels) {
         g.max_cand = g.n_cells * cell_cap;
+        if (g.max_cand > 0xFFFFFF) return ORBX_E_GEOMETRY;  // the quadtree packs a candidate's index into 24 bits
         dense_total += g.max_cand;
         kp_total += g.max_kp;
     }
@@ -210,10 +243,6 @@ int set_geometry(orbx_ctx* c, int w, int h) {
     rc = ensure(c, &c->d_tiles, tiles.size() * sizeof(TileDesc));
     if (rc) return rc;
     HIP_TRY(c, hipMemcpy(c->d_tiles.p, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
-    if (fast_lds > 64 * 1024) {
-        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_tiles),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_lds));
-    }
     for (int l = 0; l < c->tab.nlevels; ++l) {
         c->pitch[l] = (int)align_up((size_t)levels[l].w, 64);
         c->plane[l] = (size_t)c->pitch[l] * levels[l].h;
@@ -257,10 +286,6 @@ int set_geometry(orbx_ctx* c, int w, int h) {
         if (rc) return rc;
         HIP_TRY(c, hipMemcpy(c->d_xt[l].p, xt.data(), xt.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(c->d_yt[l].p, yt.data(), yt.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
-    }
-    if (oct_lds > 64 * 1024) {
-        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)oct_lds));
     }
     c->levels.swap(levels);
     c->cells.swap(cells);
@@ -399,6 +424,24 @@ void fill_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_p
     }
 }
 
+// The auxiliary and the descriptor stream with the events that order them (see run_batch).
+int ensure_aux_streams(orbx_ctx* c) {
+    if (c->aux_made) return ORBX_OK;
+    // All streams at the default priority: with low-priority streams a wait on one of them from a
+    // default-priority stream stalled for tens of seconds (measured with the chunked host path).
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->st_aux, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pyr_done, hipEventDisableTiming));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->st_desc, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_blur_done, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fast_done, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_oct_done, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_desc[0], hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_desc[1], hipEventDisableTiming));
+    c->aux_made = true;
+    return ORBX_OK;
+}
+
 // Enqueues the whole path for n frames (see fill_batch) on the context's stream.
 int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_plane, orbx_kp* d_kps, int kp_cap,
               uint8_t* d_desc, int32_t* d_n_out, int arena_set, int kp_set, int n_total = -1, int frame0 = 0,
@@ -414,25 +457,12 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     // quadtree and the blur have finished.  The memory-bound pyramid and blur so fill what the
     // VALU-bound FAST and the latency-bound quadtree leave idle, and the next batch, which works in
     // the other set of arenas, is detected while this one is described.
-    // ORBX_NO_OVERLAP=1 puts everything on the main stream in stage order.
-    const bool overlap = std::getenv("ORBX_NO_OVERLAP") == nullptr;
+    // The no-overlap switch (ORBX_NO_OVERLAP=1) puts everything on the main stream in stage order.
+    const bool overlap = !c->dbg_no_overlap;
     hipStream_t st = c->stream;
-    if (overlap && !c->aux_made) {
-        // All streams at the default priority: with low-priority streams a wait on one of them from a
-        // default-priority stream stalled for tens of seconds (measured with the chunked host path).
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->st_aux, hipStreamNonBlocking));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pyr_done, hipEventDisableTiming));
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->st_desc, hipStreamNonBlocking));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_blur_done, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fast_done, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_oct_done, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_desc[0], hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_desc[1], hipEventDisableTiming));
-        c->aux_made = true;
-    }
+    if (overlap) { int rc_ = ensure_aux_streams(c); if (rc_) return rc_; }
     hipStream_t aux = overlap ? c->st_aux : st;
-    const bool prof = c->profiling;
+    const bool prof = c->profiling && !c->capturing;  // timing events are not captured into a graph
     auto mark = [&](int i, hipStream_t s) -> int {  // timing event i (see orbx_get_stage_ms)
         if (prof) HIP_TRY(c, hipEventRecord(c->ev[i], s));
         return ORBX_OK;
@@ -457,8 +487,8 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     for (int l = 1; l < L; ++l) {
         const LevelDev& S = B.lv[l - 1];
         const LevelDev& D = B.lv[l];
-        // ORBX_RESIZE_TILES=1 (diagnostic) keeps the LDS-tiled kernel for every level
-        if (c->rs_stream[l] && std::getenv("ORBX_RESIZE_TILES") == nullptr && S.pitch >= 8 &&
+        // the resize-tiles switch (diagnostic) keeps the LDS-tiled kernel for every level
+        if (c->rs_stream[l] && !c->dbg_resize_tiles && S.pitch >= 8 &&
             (uint64_t)n * S.plane < 0x7FFFFFF0ull) {
             const int nd = (D.w + 3) / 4;
             // destination rows per lane: long bands filter fewer source rows twice, short ones give
@@ -546,13 +576,34 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     return ORBX_OK;
 }
 
+// Per-pair scratch of the stereo stage (see StereoDev); every word the kernels read they wrote first.
+struct StereoScratch {
+    uint32_t* row_start;
+    StereoMeta* meta;
+    int32_t* wmax;
+    int32_t* sad;
+};
+// The context's own (grown on demand) scratch for n_pairs pairs of kp_cap keypoints and `rows` image rows.
+int stereo_scratch_ctx(orbx_ctx* l, int n_pairs, int kp_cap, int rows, StereoScratch* out) {
+    int rc;
+    if ((rc = ensure(l, &l->d_st_rows, (size_t)n_pairs * (rows + 1) * 4))) return rc;
+    if ((rc = ensure(l, &l->d_st_meta, (size_t)n_pairs * kp_cap * sizeof(StereoMeta)))) return rc;
+    if ((rc = ensure(l, &l->d_st_wmax, (size_t)n_pairs * 4))) return rc;
+    if ((rc = ensure(l, &l->d_st_sad, (size_t)n_pairs * kp_cap * 4))) return rc;
+    out->row_start = (uint32_t*)l->d_st_rows.p;
+    out->meta = (StereoMeta*)l->d_st_meta.p;
+    out->wmax = (int32_t*)l->d_st_wmax.p;
+    out->sad = (int32_t*)l->d_st_sad.p;
+    return ORBX_OK;
+}
+
 // Enqueues the stereo stage for n_pairs pairs on `l`'s stream.  Left images are first_l + p*step of
 // `l`'s last batch, right images first_r + p*step of `r`'s; keypoints/descriptors/counts of pair p
 // are at kps_x + p*kp_step (descriptors 32 bytes each, counts at n_x[p*n_step]).
 int run_stereo(orbx_ctx* l, orbx_ctx* r, int n_pairs, int first_l, int first_r, int step, const orbx_kp* kps_l,
                const orbx_kp* kps_r, const uint8_t* desc_l, const uint8_t* desc_r, const int32_t* n_l,
                const int32_t* n_r, int64_t kp_step, int n_step, int kp_cap, float mb, float mbf, float* d_u_right,
-               float* d_depth) {
+               float* d_depth, const StereoScratch& scr) {
     const BatchDev& BL = l->B;
     const BatchDev& BR = r->B;
     const int L = BL.nlevels;
@@ -586,17 +637,12 @@ int run_stereo(orbx_ctx* l, orbx_ctx* r, int n_pairs, int first_l, int first_r, 
     S.rows = BL.lv[0].h;
     S.max_d = mbf / mb;  // :517, float division
     S.mbf = mbf;
-    // diagnostic: ORBX_STEREO_BORDER_PATH=1 loads every window through the reflecting byte loader
-    S.border_only = std::getenv("ORBX_STEREO_BORDER_PATH") != nullptr;
-    int rc;
-    if ((rc = ensure(l, &l->d_st_rows, (size_t)n_pairs * (S.rows + 1) * 4))) return rc;
-    if ((rc = ensure(l, &l->d_st_meta, (size_t)n_pairs * kp_cap * sizeof(StereoMeta)))) return rc;
-    if ((rc = ensure(l, &l->d_st_wmax, (size_t)n_pairs * 4))) return rc;
-    if ((rc = ensure(l, &l->d_st_sad, (size_t)n_pairs * kp_cap * 4))) return rc;
-    S.row_start = (uint32_t*)l->d_st_rows.p;
-    S.meta = (StereoMeta*)l->d_st_meta.p;
-    S.wmax = (int32_t*)l->d_st_wmax.p;
-    S.sad = (int32_t*)l->d_st_sad.p;
+    // diagnostic switch: every window is loaded through the reflecting byte loader
+    S.border_only = l->dbg_stereo_border ? 1 : 0;
+    S.row_start = scr.row_start;
+    S.meta = scr.meta;
+    S.wmax = scr.wmax;
+    S.sad = scr.sad;
     S.u_right = d_u_right;
     S.depth = d_depth;
     hipStream_t st = l->stream;
@@ -666,7 +712,7 @@ int extract_batch_pipelined(orbx_ctx* c, int n, const uint8_t* const* imgs, int 
     const size_t plane = c->plane[0];
     const int pitch = c->pitch[0];
     int m = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, kPipeChunkBytes / plane));
-    if (const char* e = std::getenv("ORBX_PIPE_CHUNK")) m = std::max(1, std::min(n, std::atoi(e)));  // frames per chunk (tests)
+    if (c->dbg_pipe_chunk > 0) m = std::max(1, std::min(n, c->dbg_pipe_chunk));  // frames per chunk (tests)
     const size_t res_kps = (size_t)m * cap * sizeof(orbx_kp), res_desc = (size_t)m * cap * 32, res_cnt = (size_t)m * 4;
     int rc = ensure_pipeline(c, (size_t)m * plane, res_kps + res_desc + res_cnt);
     if (rc) return rc;
@@ -694,7 +740,7 @@ int extract_batch_pipelined(orbx_ctx* c, int n, const uint8_t* const* imgs, int 
         return ORBX_OK;
     };
 
-    const bool ptrace = std::getenv("ORBX_TRACE") != nullptr;
+    const bool ptrace = c->dbg_trace;
     auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tp0 = tnow();
     for (int k = 0; k < nchunks; ++k) {
@@ -740,6 +786,100 @@ int extract_batch_pipelined(orbx_ctx* c, int n, const uint8_t* const* imgs, int 
     return ORBX_OK;
 }
 
+// One frame from host memory as ONE graph launch: upload, the whole launch sequence of run_batch on
+// its three streams, and the download of the results are captured once per image size and replayed
+// per call, so that a small image costs one submission instead of thirteen launches and a dozen
+// event operations.  Everything the graph touches is fixed for the life of the graph: pinned input
+// and output buffers of its own, arena set 0, retained-point set 0, the context's result buffers.
+int build_graph(orbx_ctx* c, int width, int height, int cap) {
+    drop_graph(c);
+    int rc = sync_ctx(c);  // no event of an earlier batch may be waited for inside the capture
+    if (rc) return rc;
+    if ((rc = ensure_aux_streams(c))) return rc;
+    const size_t plane = c->plane[0];
+    const size_t out_bytes = (size_t)cap * (sizeof(orbx_kp) + 32) + 4;
+    HIP_TRY(c, hipHostMalloc(&c->h_gin, plane, hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc(&c->h_gout, out_bytes, hipHostMallocDefault));
+    std::memset(c->h_gin, 0, plane);
+    c->arena_desc[0] = c->arena_desc[1] = -1;
+    hipGraph_t graph = nullptr;
+    HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    c->capturing = true;
+    auto body = [&]() -> int {
+        HIP_TRY(c, hipMemcpyAsync(c->d_pyr[0].p, c->h_gin, plane, hipMemcpyHostToDevice, c->stream));
+        int rc_ = run_batch(c, 1, nullptr, 0, 0, (orbx_kp*)c->d_out_kps.p, cap, (uint8_t*)c->d_out_desc.p,
+                            (int32_t*)c->d_out_n.p, 0, 0, -1, 0, true);
+        if (rc_) return rc_;
+        if ((rc_ = join(c))) return rc_;  // the descriptor stream rejoins the capturing stream
+        uint8_t* o = (uint8_t*)c->h_gout;
+        HIP_TRY(c, hipMemcpyAsync(o, c->d_out_kps.p, (size_t)cap * sizeof(orbx_kp), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(o + (size_t)cap * sizeof(orbx_kp), c->d_out_desc.p, (size_t)cap * 32, hipMemcpyDeviceToHost,
+                                  c->stream));
+        HIP_TRY(c, hipMemcpyAsync(o + (size_t)cap * (sizeof(orbx_kp) + 32), c->d_out_n.p, 4, hipMemcpyDeviceToHost, c->stream));
+        return ORBX_OK;
+    };
+    rc = body();
+    const hipError_t e_end = hipStreamEndCapture(c->stream, &graph);
+    c->capturing = false;
+    c->desc_pending[0] = c->desc_pending[1] = false;
+    c->arena_desc[0] = c->arena_desc[1] = -1;
+    c->have_last = false;  // nothing has run yet
+    if (rc == ORBX_OK && e_end != hipSuccess) {
+        c->last_hip = (int)e_end;
+        rc = ORBX_E_HIP;
+    }
+    if (rc == ORBX_OK) {
+        const hipError_t e_inst = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
+        if (e_inst != hipSuccess) {
+            c->last_hip = (int)e_inst;
+            c->graph_exec = nullptr;
+            rc = ORBX_E_HIP;
+        }
+    }
+    if (graph) (void)hipGraphDestroy(graph);
+    if (rc) {
+        drop_graph(c);
+        return rc;
+    }
+    c->graph_w = width;
+    c->graph_h = height;
+    c->graph_cap = cap;
+    return ORBX_OK;
+}
+
+int extract_graph(orbx_ctx* c, const uint8_t* img, int width, int height, int stride, orbx_kp* kps, int kp_cap,
+                  uint8_t* desc, int* n_out, int cap) {
+    int rc;
+    if (!c->graph_exec || c->graph_w != width || c->graph_h != height || c->graph_cap != cap) {
+        if ((rc = build_graph(c, width, height, cap))) return rc;
+    } else if ((rc = sync_ctx(c))) {  // an earlier asynchronous batch may still use arena set 0
+        return rc;
+    }
+    const int pitch = c->pitch[0];
+    for (int y = 0; y < height; ++y) std::memcpy((uint8_t*)c->h_gin + (size_t)y * pitch, img + (size_t)y * stride, (size_t)width);
+    HIP_TRY(c, hipGraphLaunch(c->graph_exec, c->stream));
+    // the host-side view of the batch the graph computes (read-backs and the stereo stage use it)
+    fill_batch(c, 1, nullptr, 0, 0, 1, 0, 0);
+    c->arena_set = 0;
+    c->kp_set = 0;
+    c->last_kps = (orbx_kp*)c->d_out_kps.p;
+    c->last_desc = (uint8_t*)c->d_out_desc.p;
+    c->last_n = (int32_t*)c->d_out_n.p;
+    c->last_kp_cap = cap;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->have_last = true;
+    const uint8_t* o = (const uint8_t*)c->h_gout;
+    int32_t k = 0;
+    std::memcpy(&k, o + (size_t)cap * (sizeof(orbx_kp) + 32), 4);
+    k = std::max(0, std::min(k, std::min(cap, kp_cap)));
+    *n_out = k;
+    if (k > 0) {
+        std::memcpy(kps, o, (size_t)k * sizeof(orbx_kp));
+        std::memcpy(desc, o + (size_t)cap * sizeof(orbx_kp), (size_t)k * 32);
+    }
+    return ORBX_OK;
+}
+
 int check_call(orbx_ctx* c, int n, int w, int h, int kp_cap) {
     if (!c || n < 1 || w < 1 || h < 1) return ORBX_E_INVALID;
     if (n > c->prm.max_batch || n > 65535) return ORBX_E_CAPACITY;
@@ -771,6 +911,13 @@ extern "C" int orbx_create(const orbx_params* params, orbx_ctx** out) {
     if (!c) return ORBX_E_INVALID;
     c->prm = *params;
     c->tab = tab;
+    // diagnostic switches: the environment is read here, once, and never on the per-batch path
+    c->dbg_no_overlap = std::getenv("ORBX_NO_OVERLAP") != nullptr;
+    c->dbg_resize_tiles = std::getenv("ORBX_RESIZE_TILES") != nullptr;
+    c->dbg_stereo_border = std::getenv("ORBX_STEREO_BORDER_PATH") != nullptr;
+    c->dbg_trace = std::getenv("ORBX_TRACE") != nullptr;
+    c->dbg_no_graph = std::getenv("ORBX_NO_GRAPH") != nullptr;
+    if (const char* e = std::getenv("ORBX_PIPE_CHUNK")) c->dbg_pipe_chunk = std::max(0, std::atoi(e));
     int rc = ORBX_OK;
     auto fail = [&](int code) {
         orbx_destroy(c);
@@ -781,6 +928,11 @@ extern "C" int orbx_create(const orbx_params* params, orbx_ctx** out) {
     for (int i = 0; i < kEvCount; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(ORBX_E_HIP);
     c->ev_made = true;
+    // every context sets the same limit, so a later context cannot lower what an earlier one relies on
+    for (const void* fn : {reinterpret_cast<const void*>(k_fast_tiles), reinterpret_cast<const void*>(k_octree),
+                           reinterpret_cast<const void*>(k_bow_vectors)})
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds) != hipSuccess)
+            return fail(ORBX_E_HIP);
     {
         std::vector<uint32_t> tab((size_t)kDescTabVec * 64 * 4);
         build_describe_lane_table(kPattern, tab.data());
@@ -802,6 +954,7 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->prm.device_id);
     if (c->stream) (void)sync_ctx(c);
+    drop_graph(c);
 #if defined(ORBX_STAMPS) || defined(ORBX_STAMPS_DESC)
     if (c->d_stamps.p) {
         std::vector<unsigned long long> h(1024 * 16);
@@ -885,7 +1038,7 @@ extern "C" int orbx_extract_batch(orbx_ctx* c, int n, const uint8_t* const* imgs
     if (rc) return rc;
     for (int i = 0; i < n; ++i)
         if (!imgs[i] || strides[i] < width) return ORBX_E_INVALID;
-    const bool trace = std::getenv("ORBX_TRACE") != nullptr;
+    const bool trace = c->dbg_trace;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_a = now();
     if ((rc = ensure_arenas(c, n, true))) return rc;
@@ -893,6 +1046,8 @@ extern "C" int orbx_extract_batch(orbx_ctx* c, int n, const uint8_t* const* imgs
     if ((rc = ensure(c, &c->d_out_kps, (size_t)n * cap * sizeof(orbx_kp)))) return rc;
     if ((rc = ensure(c, &c->d_out_desc, (size_t)n * cap * 32))) return rc;
     if ((rc = ensure(c, &c->d_out_n, (size_t)n * 4))) return rc;
+    if (n == 1 && !c->dbg_no_graph && !c->dbg_no_overlap && !c->profiling)
+        return extract_graph(c, imgs[0], width, height, strides[0], kps, kp_cap, desc, n_out, cap);
     if (n >= kPipeMinFrames) {
         rc = extract_batch_pipelined(c, n, imgs, width, height, strides, kps, kp_cap, desc, n_out, cap);
         if (trace) std::fprintf(stderr, "orbx_extract_batch (pipelined) host ms: %.3f\n", now() - t_a);
@@ -944,9 +1099,11 @@ extern "C" int orbx_stereo_match_batch_device(orbx_ctx* c, int n_pairs, const or
     HIP_TRY(c, hipSetDevice(c->prm.device_id));
     int rc = join(c);  // the descriptors of the batch may still be running on the auxiliary stream
     if (rc) return rc;
+    StereoScratch scr;
+    if ((rc = stereo_scratch_ctx(c, n_pairs, kp_cap, c->B.lv[0].h, &scr))) return rc;
     // pair p = images (2p, 2p + 1) of the last batch; their results are 2 * kp_cap keypoints apart
     rc = run_stereo(c, c, n_pairs, 0, 1, 2, d_kps, d_kps + kp_cap, d_desc, d_desc + (size_t)kp_cap * 32, d_n, d_n + 1,
-                        2 * (int64_t)kp_cap, 2, kp_cap, mb, mbf, d_u_right, d_depth);
+                        2 * (int64_t)kp_cap, 2, kp_cap, mb, mbf, d_u_right, d_depth, scr);
     if (rc) return rc;
     if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     return ORBX_OK;
@@ -965,6 +1122,9 @@ extern "C" int orbx_stereo_match(orbx_ctx* left, int img_left, orbx_ctx* right, 
         return ORBX_E_INVALID;
     HIP_TRY(left, hipSetDevice(left->prm.device_id));
     { int rc_ = sync_ctx(right); if (rc_) return rc_; }  // the right extraction has finished
+    // the left one may have been enqueued without waiting (orbx_extract_batch_device, sync = 0): its
+    // descriptors run on their own stream, which the main stream must wait for before it reads them
+    { int rc_ = join(left); if (rc_) return rc_; }
     const int kp_cap = left->last_kp_cap;
     if (kp_cap > 65535) return ORBX_E_CAPACITY;
     int32_t nl = 0;
@@ -972,10 +1132,12 @@ extern "C" int orbx_stereo_match(orbx_ctx* left, int img_left, orbx_ctx* right, 
     int rc;
     if ((rc = ensure(left, &left->d_st_u, (size_t)kp_cap * 4))) return rc;
     if ((rc = ensure(left, &left->d_st_depth, (size_t)kp_cap * 4))) return rc;
+    StereoScratch scr;
+    if ((rc = stereo_scratch_ctx(left, 1, kp_cap, left->B.lv[0].h, &scr))) return rc;
     rc = run_stereo(left, right, 1, img_left, img_right, 0, left->last_kps + (size_t)img_left * kp_cap,
                     right->last_kps + (size_t)img_right * kp_cap, left->last_desc + (size_t)img_left * kp_cap * 32,
                     right->last_desc + (size_t)img_right * kp_cap * 32, left->last_n + img_left, right->last_n + img_right, 0,
-                    0, kp_cap, mb, mbf, (float*)left->d_st_u.p, (float*)left->d_st_depth.p);
+                    0, kp_cap, mb, mbf, (float*)left->d_st_u.p, (float*)left->d_st_depth.p, scr);
     if (rc) return rc;
     { int rc_ = sync_ctx(left); if (rc_) return rc_; }
     *n_left = nl;
@@ -1155,9 +1317,6 @@ extern "C" int orbx_bow_transform_batch_device(orbx_ctx* c, orbx_voc* v, int n, 
     while (P < kp_cap) P <<= 1;
     const int dual = (size_t)P * 16 <= 128 * 1024 ? 1 : 0;
     const size_t lds = (size_t)P * (dual ? 16 : 8);
-    if (lds > 64 * 1024)
-        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bow_vectors), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds));
     hipLaunchKernelGGL(k_bow_vectors, dim3(n), dim3(1024), lds, c->stream, V, d_n, kp_cap, P, dual, (const uint32_t*)d_word,
                        (const uint32_t*)d_node, (const double*)d_weight, d_bow_id, d_bow_val, d_bow_n, d_fv_node, d_fv_idx,
                        d_fv_n);
@@ -1312,6 +1471,23 @@ extern "C" int orbx_debug_read(orbx_ctx* c, int what, int img_idx, int level, vo
         return ORBX_OK;
     }
     return ORBX_E_INVALID;
+}
+
+extern "C" int orbx_set_debug_flag(orbx_ctx* c, int flag, int value) {
+    if (!c) return ORBX_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    { int rc_ = sync_ctx(c); if (rc_) return rc_; }  // a switch never changes under work in flight
+    switch (flag) {
+        case ORBX_FLAG_NO_OVERLAP: c->dbg_no_overlap = value != 0; break;
+        case ORBX_FLAG_RESIZE_TILES: c->dbg_resize_tiles = value != 0; break;
+        case ORBX_FLAG_STEREO_BORDER_PATH: c->dbg_stereo_border = value != 0; break;
+        case ORBX_FLAG_TRACE: c->dbg_trace = value != 0; break;
+        case ORBX_FLAG_NO_GRAPH: c->dbg_no_graph = value != 0; break;
+        case ORBX_FLAG_PIPE_CHUNK: c->dbg_pipe_chunk = std::max(0, value); break;
+        default: return ORBX_E_INVALID;
+    }
+    drop_graph(c);  // captured with the old switches
+    return ORBX_OK;
 }
 
 extern "C" int orbx_set_profiling(orbx_ctx* c, int enable) {

@@ -3,14 +3,41 @@
 //   harness extract <nf> <scale> <nl> <ini> <min> <w> <h> <stride> <in.raw> <out.bin>
 //   harness stereo <nf> <scale> <nl> <w> <h> <left.raw> <right.raw> <mb> <mbf> <out.bin>
 //       out.bin: int32 N, N floats mvuRight, N floats mvDepth
+//   harness threads <nf> <scale> <nl> <w> <h> <pairs> <frames.raw> <mb> <mbf> <out.bin> <threaded 0|1>
+//       frames.raw: 2*pairs frames (left, right, left, ...).  Two extractor instances live for the whole
+//       run; per pair each one is called from a thread of its own that is created for the call and
+//       joined after it (threaded = 1; the calling thread does both calls when 0), then the left
+//       instance matches against the right.  out.bin per pair: int32 Kl, Kl*28 + Kl*32 bytes, int32 Kr,
+//       Kr*28 + Kr*32 bytes, int32 N, N floats mvuRight, N floats mvDepth.
 // extract's out.bin: int32 K, K*28 bytes keypoints (cv::KeyPoint field order), K*32 bytes descriptors,
 // then per level: int32 w, int32 h, (w+38)*(h+38) bytes of the padded pyramid buffer.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "ORBextractor.h"
+
+namespace {
+struct Extraction {
+    std::vector<cv::KeyPoint> kps;
+    cv::Mat desc;
+};
+// The body of Frame::ExtractORB (reference src/Frame.cc:249-255).
+void ExtractORB(ORB_SLAM2::ORBextractor* ex, const cv::Mat* im, Extraction* out) { (*ex)(*im, cv::Mat(), out->kps, out->desc); }
+void WriteExtraction(FILE* o, const Extraction& e) {
+    int K = (int)e.kps.size();
+    std::fwrite(&K, 4, 1, o);
+    for (int i = 0; i < K; i++) {
+        float v[5] = {e.kps[i].pt.x, e.kps[i].pt.y, e.kps[i].size, e.kps[i].angle, e.kps[i].response};
+        int q[2] = {e.kps[i].octave, e.kps[i].class_id};
+        std::fwrite(v, 4, 5, o);
+        std::fwrite(q, 4, 2, o);
+    }
+    for (int i = 0; i < K; i++) std::fwrite(e.desc.ptr(i), 1, 32, o);
+}
+}  // namespace
 
 int main(int argc, char** argv) {
     if (argc >= 5 && !std::strcmp(argv[1], "tables")) {
@@ -87,6 +114,48 @@ int main(int argc, char** argv) {
         if (N) {
             std::fwrite(&u[0], 4, (size_t)N, o);
             std::fwrite(&d[0], 4, (size_t)N, o);
+        }
+        std::fclose(o);
+        return 0;
+    }
+    if (argc >= 13 && !std::strcmp(argv[1], "threads")) {
+        const int nf = std::atoi(argv[2]), nl = std::atoi(argv[4]);
+        const float sc = (float)std::atof(argv[3]);
+        const int w = std::atoi(argv[5]), h = std::atoi(argv[6]), pairs = std::atoi(argv[7]);
+        const bool threaded = std::atoi(argv[12]) != 0;
+        std::vector<unsigned char> raw((size_t)w * h * 2 * pairs);
+        FILE* f = std::fopen(argv[8], "rb");
+        if (!f || std::fread(&raw[0], 1, raw.size(), f) != raw.size()) return 2;
+        std::fclose(f);
+        FILE* o = std::fopen(argv[11], "wb");
+        if (!o) return 4;
+        // the two instances Tracking keeps for the STEREO sensor (reference src/Tracking.cc:121-125)
+        ORB_SLAM2::ORBextractor left(nf, sc, nl, 20, 7), right(nf, sc, nl, 20, 7);
+        for (int p = 0; p < pairs; p++) {
+            cv::Mat iml(h, w, CV_8UC1, &raw[(size_t)(2 * p) * w * h], (size_t)w);
+            cv::Mat imr(h, w, CV_8UC1, &raw[(size_t)(2 * p + 1) * w * h], (size_t)w);
+            Extraction el, er;
+            if (threaded) {
+                // Frame::Frame (stereo), reference src/Frame.cc:78-81: two threads per frame, joined
+                std::thread tl(ExtractORB, &left, &iml, &el);
+                std::thread tr(ExtractORB, &right, &imr, &er);
+                tl.join();
+                tr.join();
+            } else {
+                ExtractORB(&left, &iml, &el);
+                ExtractORB(&right, &imr, &er);
+            }
+            std::vector<float> u, d;
+            left.ComputeStereoMatches(right, (float)std::atof(argv[9]), (float)std::atof(argv[10]), u, d);
+            if (u.size() != el.kps.size() || d.size() != el.kps.size()) return 5;
+            WriteExtraction(o, el);
+            WriteExtraction(o, er);
+            int N = (int)u.size();
+            std::fwrite(&N, 4, 1, o);
+            if (N) {
+                std::fwrite(&u[0], 4, (size_t)N, o);
+                std::fwrite(&d[0], 4, (size_t)N, o);
+            }
         }
         std::fclose(o);
         return 0;

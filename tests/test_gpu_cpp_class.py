@@ -74,3 +74,61 @@ def test_cpp_stereo_extension_matches_oracle(oracle, tmp_path):
     ou, od, _, kept = oracle.stereo_match(ol, orr, np.float32(mb), np.float32(mbf))
     assert n == len(kl) and kept > 100
     assert (u == ou.view(np.uint32)).all() and (d == od.view(np.uint32)).all()
+
+
+def _read_extraction(blob, off):
+    k = int(np.frombuffer(blob, np.int32, 1, off)[0])
+    kps = np.frombuffer(blob, KP, k, off + 4)
+    desc = np.frombuffer(blob, np.uint8, k * 32, off + 4 + 28 * k).reshape(k, 32)
+    return kps, desc, off + 4 + 60 * k
+
+
+def test_cpp_two_threads_two_instances(oracle, tmp_path):
+    """The STEREO calling pattern of the reference (src/Frame.cc:78-81): two extractor instances that live
+    for the whole sequence, each called from a thread of its own that is created for the frame and
+    joined after it, 50 frame pairs in a row, then the stereo association across the two instances.
+    Every pair equals the oracle bit for bit, and the whole output file equals that of the same
+    sequence run from one thread."""
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")])
+    w, h, nf, nl, pairs = 640, 480, 1000, 8, 50
+    rng = np.random.default_rng(5)
+    wide = synth.make_batch(10, w + 32, h, 1, 500)
+    frames = np.zeros((2 * pairs, h, w), np.uint8)
+    for p in range(pairs):
+        s = 3 + p % 9
+        frames[2 * p] = wide[p % 10][:, :w] if p < 25 else 255 - wide[p % 10][:, :w]
+        right = wide[p % 10][:, s:w + s].astype(np.int32) + rng.integers(-2, 3, (h, w))
+        frames[2 * p + 1] = np.clip(right if p < 25 else 255 - right, 0, 255).astype(np.uint8)
+    raw = tmp_path / "frames.raw"
+    frames.tofile(raw)
+    mb, mbf = 0.11, 47.9
+    blobs = []
+    for threaded in (1, 0):
+        out = tmp_path / ("out%d.bin" % threaded)
+        subprocess.check_call([EXE, "threads", str(nf), "1.2", str(nl), str(w), str(h), str(pairs), str(raw), repr(mb),
+                               repr(mbf), str(out), str(threaded)], timeout=300)
+        blobs.append(out.read_bytes())
+    assert blobs[0] == blobs[1], "two threads and one thread disagree"
+    blob, off = blobs[0], 0
+    ol, orr = oracle.Oracle(nf, 1.2, nl, 20, 7), oracle.Oracle(nf, 1.2, nl, 20, 7)
+    matched = 0
+    for p in range(pairs):
+        kl, dl, off = _read_extraction(blob, off)
+        kr, dr, off = _read_extraction(blob, off)
+        n = int(np.frombuffer(blob, np.int32, 1, off)[0])
+        u = np.frombuffer(blob, np.uint32, n, off + 4)
+        d = np.frombuffer(blob, np.uint32, n, off + 4 + 4 * n)
+        off += 4 + 8 * n
+        okl, odl = ol.extract(frames[2 * p])
+        okr, odr = orr.extract(frames[2 * p + 1])
+        for got, exp in ((kl, okl), (kr, okr)):
+            assert len(got) == len(exp), p
+            for f in KP.names:
+                assert (got[f] == exp[f]).all(), (p, f)
+        assert (dl == odl).all() and (dr == odr).all(), p
+        ou, od, _, kept = oracle.stereo_match(ol, orr, np.float32(mb), np.float32(mbf))
+        assert n == len(okl)
+        assert (u == ou.view(np.uint32)).all() and (d == od.view(np.uint32)).all(), p
+        matched += kept
+    assert off == len(blob) and matched > 50 * pairs

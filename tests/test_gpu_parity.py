@@ -339,6 +339,74 @@ def test_device_input_unaligned(oracle):
         a.free()
 
 
+def test_quadtree_nodes_above_65535_points(oracle):
+    """A 2160 x 2160 frame of single-pixel dots four pixels apart: every dot is a FAST corner that survives
+    the suppression, so level 0 has a quarter of a million candidates under ONE quadtree root.  The first
+    sweep leaves four nodes; with a level-0 quota of 5 the one-at-a-time phase then splits exactly one of
+    them, the largest.  Rows of dots are removed so that the upper left node (70225 points) is the largest
+    but, modulo 65536, the smallest: the order must come from the real sizes."""
+    w, h, nf, nl = 2160, 2160, 25, 12
+    img = np.full((h, w), 100, np.uint8)
+    img[2::4, 2::4] = 200
+    img[2:2 + 4 * 24:4, w // 2:] = 100                   # upper right: 24 rows of dots less
+    img[h // 2 + 2:h // 2 + 2 + 4 * 44:4, :] = 100       # lower half: 44 rows less
+    ex = oa.ORBextractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=1, keep_pyramid=False)
+    orc = oracle.Oracle(nf, 1.2, nl, 20, 7)
+    kps, desc = ex(img)
+    okps, odesc = orc.extract(img)
+    assert ex.mnFeaturesPerLevel[0] == 5
+    cand = orc.candidates(0)
+    mx, my = (w - 32 + 1) // 2, (h - 32 + 1) // 2
+    size = [int((((cand["x"] < mx) == a) & ((cand["y"] < my) == b)).sum()) for a, b in
+            ((True, True), (False, True), (True, False), (False, False))]
+    assert size[0] > 65535 > size[1] > size[2] and (size[0] & 0xFFFF) < size[3], size
+    got = ex.debug_read(oa.DBG_LEVEL_KPS, 0, 0).view(np.int32).reshape(-1, 3)
+    assert len(got) == orc.level_keypoint_count(0) == 7
+    assert ((got[:, 0] < mx + 16) & (got[:, 1] < my + 16)).sum() == 4   # the upper left node was the one split
+    _check_final(kps, desc, okps, odesc)
+    ex.close()
+
+
+def test_single_frame_launch_graph_and_plain_launches(oracle):
+    """orbx_extract replays a captured HIP graph per image size; the no-graph switch issues the same launches
+    one by one.  Both paths, sizes changing back and forth on one context, an asynchronous device batch in
+    between (its arenas are the graph's), then the graph again: all equal to the oracle."""
+    from hip_rt import DeviceArray
+    sizes = [(640, 480, 1), (752, 480, 4), (640, 480, 1)]
+    ex = oa.ORBextractor(1000, 1.2, 8, 20, 7, max_width=752, max_height=480, max_batch=4)
+    orc = oracle.Oracle(1000, 1.2, 8, 20, 7)
+    for use_graph in (True, False, True):
+        ex.set_debug_flag(oa.FLAG_NO_GRAPH, 0 if use_graph else 1)
+        for rep, (w, h, cid) in enumerate(sizes):
+            for k in range(3):                           # the same size several times: capture once, replay
+                img = synth.make_frame(w, h, cid, 40 + 3 * rep + k)
+                kps, desc = ex(img)
+                okps, odesc = orc.extract(img)
+                _check_final(kps, desc, okps, odesc)
+            _check_stages(ex, orc, img)
+    # an asynchronous batch through the device entry point, then the graph on top of it at once
+    w, h, n = 752, 480, 4
+    host = np.zeros((n, h, 768), np.uint8)
+    host[:, :, :w] = synth.make_batch(n, w, h, 4, 70)
+    d_in = DeviceArray.from_host(host)
+    cap = ex.max_keypoints(w, h)
+    d_kps, d_desc = DeviceArray((n, cap, 28), np.uint8, fill_byte=0), DeviceArray((n, cap, 32), np.uint8, fill_byte=0)
+    d_n = DeviceArray((n,), np.int32, fill_byte=0)
+    img = synth.make_frame(w, h, 4, 90)
+    ex(img)                                              # graph captured for this size
+    ex.extract_batch_device(d_in.ptr, n, w, h, 768, h * 768, d_kps.ptr, cap, d_desc.ptr, d_n.ptr, sync=False)
+    kps, desc = ex(img)
+    _check_final(kps, desc, *orc.extract(img))
+    cnt, bk, bd = d_n.to_host(), d_kps.to_host(), d_desc.to_host()
+    for i in range(n):
+        okps, odesc = orc.extract(host[i, :, :w])
+        assert cnt[i] == len(okps)
+        _check_final(np.ascontiguousarray(bk[i, :cnt[i]]).reshape(-1).view(oa.KP_DTYPE), bd[i, :cnt[i]], okps, odesc)
+    ex.close()
+    for a in (d_in, d_kps, d_desc, d_n):
+        a.free()
+
+
 def test_errors():
     ex = oa.ORBextractor(500, 1.2, 8, 20, 7, max_width=320, max_height=240)
     with pytest.raises(oa.OrbxError):

@@ -21,16 +21,19 @@ desc = np.zeros((cap, 32), np.uint8)
 n = C.c_int(0)
 args = (ex._ctx, img.ctypes.data_as(C.c_void_p), w, h, img.strides[0], kps.ctypes.data_as(C.c_void_p), cap,
         desc.ctypes.data_as(C.c_void_p), C.byref(n))
-for _ in range(20):
-    L.orbx_extract(*args)
-t = []
-for _ in range(500):
-    t0 = time.perf_counter()
-    L.orbx_extract(*args)
-    t.append(time.perf_counter() - t0)
-t = np.array(t) * 1e3
-print("orbx_extract %dx%d: median %.3f ms p10 %.3f p90 %.3f, %d keypoints" % (w, h, np.median(t), np.percentile(t, 10),
-                                                                            np.percentile(t, 90), n.value))
+reps = int(sys.argv[4]) if len(sys.argv) >= 5 else 1000
+for name, no_graph in (("one HIP graph launch per call", 0), ("launches issued one by one", 1)):
+    ex.set_debug_flag(oa.FLAG_NO_GRAPH, no_graph)
+    for _ in range(20):
+        L.orbx_extract(*args)
+    t = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        L.orbx_extract(*args)
+        t.append(time.perf_counter() - t0)
+    t = np.array(t) * 1e3
+    print("orbx_extract %dx%d, %s: median %.3f ms p10 %.3f p90 %.3f, %d keypoints (%d calls)"
+          % (w, h, name, np.median(t), np.percentile(t, 10), np.percentile(t, 90), n.value, reps))
 ex.set_profiling(True)
 L.orbx_extract(*args)
 print("device stage ms:", ex.stage_ms())
