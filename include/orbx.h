@@ -307,6 +307,23 @@ int orbx_stereo_match_batch_device(orbx_ctx* ctx, int n_pairs, const orbx_kp* d_
                                    const uint8_t* d_desc, const int32_t* d_n, float mb, float mbf,
                                    float* d_u_right, float* d_depth, int sync);
 
+/* orbx_stereo_match_batch_device for callers that cannot allocate device memory: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the
+ * reference.  Same arguments, same results; the kernels' scratch (row table, bucketed right
+ * keypoints, window distances) lives in a fixed array inside the library instead of buffers the
+ * context grows on demand, and the call makes no hipMalloc, hipFree or other allocating call.
+ * Limit: n_pairs * (4 * (image rows + 1) + 16 * kp_cap + 4) bytes, each of the four parts rounded
+ * up to 256, must fit ORBX_NOALLOC_SCRATCH_BYTES (8 MiB: 248 KITTI-shape pairs at kp_cap 2008);
+ * beyond that, or kp_cap > 16384, the call returns ORBX_E_CAPACITY and does nothing.  Each GPU
+ * the library runs on holds one copy of the array until the process ends, and every call on
+ * that GPU -- from any context -- uses it: two such calls that overlap in time on one GPU race,
+ * so synchronise one before the next is enqueued (calls on one context are stream-ordered and
+ * safe).  Nothing in the array has to start at zero; it keeps the last call's contents. */
+#define ORBX_NOALLOC_SCRATCH_BYTES ((size_t)8 << 20)
+int orbx_stereo_match_batch_device_noalloc(orbx_ctx* ctx, int n_pairs, const orbx_kp* d_kps, int kp_cap,
+                                           const uint8_t* d_desc, const int32_t* d_n, float mb, float mbf,
+                                           float* d_u_right, float* d_depth, int sync);
+
 /* Copies pyramid level `level` of image `img_idx` of the LAST extraction to host memory
  * (un-padded, rows dst_stride apart).  Replaces reads of the public member mvImagePyramid
  * (reference include/ORBextractor.h:85; read by src/Frame.cc:492,582,594,599). */

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "liborbx.so")
 MAX_LEVELS = 16
 NUM_STAGES = 5
 EDGE_THRESHOLD = 19
+NOALLOC_SCRATCH_BYTES = 8 << 20
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
@@ -52,6 +53,7 @@ EXPORTS = [
     "orbx_undistort_grid_batch_device",
     "orbx_voc_create", "orbx_voc_load_text", "orbx_voc_destroy", "orbx_voc_info", "orbx_voc_node", "orbx_bow_transform_batch_device", "orbx_search_window_batch_device",
     "orbx_search_by_projection_batch_device", "orbx_set_debug_flag",
+    "orbx_stereo_match_batch_device_noalloc",
 ]
 
 _lib = None
@@ -80,6 +82,7 @@ def load_library():
     L.orbx_synchronize.argtypes = [vp]
     L.orbx_stereo_match.argtypes = [vp, i32, vp, i32, f32, f32, vp, vp, i32, C.POINTER(i32)]
     L.orbx_stereo_match_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, f32, f32, vp, vp, i32]
+    L.orbx_stereo_match_batch_device_noalloc.argtypes = [vp, i32, vp, i32, vp, vp, f32, f32, vp, vp, i32]
     L.orbx_undistort_grid_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, f32, f32, f32, f32, vp, vp, vp, i32]
     L.orbx_voc_create.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, vp, C.POINTER(vp)]
     L.orbx_voc_load_text.argtypes = [C.c_char_p, C.POINTER(vp)]
@@ -357,6 +360,15 @@ class ORBextractor:
         _check(self._L.orbx_stereo_match_batch_device(self._ctx, n_pairs, C.c_void_p(d_kps), kp_cap, C.c_void_p(d_desc),
                                                       C.c_void_p(d_n), mb, mbf, C.c_void_p(d_u_right),
                                                       C.c_void_p(d_depth), int(sync)), self._ctx)
+
+    def stereo_match_batch_device_noalloc(self, n_pairs, d_kps, kp_cap, d_desc, d_n, mb, mbf, d_u_right, d_depth,
+                                          sync=True):
+        """stereo_match_batch_device with the kernels' scratch in the library's fixed array: allocates
+        nothing; sizes beyond NOALLOC_SCRATCH_BYTES raise; see orbx_stereo_match_batch_device_noalloc."""
+        _check(self._L.orbx_stereo_match_batch_device_noalloc(self._ctx, n_pairs, C.c_void_p(d_kps), kp_cap,
+                                                              C.c_void_p(d_desc), C.c_void_p(d_n), mb, mbf,
+                                                              C.c_void_p(d_u_right), C.c_void_p(d_depth), int(sync)),
+               self._ctx)
 
     # ---- pyramid read-back: the public member mvImagePyramid (include/ORBextractor.h:85) ----
     def pyramid_level(self, img_idx, level, padded=False):

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -36,6 +37,32 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // small static arrays.  The limit is a property of the kernel on a device, shared by every context,
 // so it is set to this one value and never to a context's own need.
 constexpr int kMaxDynamicLds = 160 * 1024 - 256;
+
+// Scratch of the entry point that allocates nothing (orbx_stereo_match_batch_device_noalloc): a
+// fixed array in the code object, one copy per GPU.  Host code reaches it only through the address
+// hipGetSymbolAddress returns for the current device (kept per device below), never by name.
+constexpr size_t kScratchBytes = ORBX_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) uint8_t scratch[kScratchBytes];
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+uint8_t* g_scratch_ptr[kMaxDevices];  // per device ordinal, null until looked up
+
+// Address of the current device's copy of `scratch` (device `dev` must be current).
+int scratch_address(int dev, uint8_t** out, int* hip_err) {
+    if (dev < 0 || dev >= kMaxDevices) return ORBX_E_INVALID;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            *hip_err = (int)e;
+            return ORBX_E_HIP;
+        }
+        g_scratch_ptr[dev] = (uint8_t*)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return ORBX_OK;
+}
 
 struct DevBuf {
     void* p = nullptr;
@@ -120,6 +147,8 @@ struct orbx_ctx {
     bool capturing = false;
     void* h_gin = nullptr;   // pinned: the frame at device pitch (source of the graph's upload node)
     void* h_gout = nullptr;  // pinned: [cap keypoints][cap descriptors][count] (target of its download nodes)
+
+    uint8_t* scratch = nullptr;  // this device's copy of the library's static scratch array
 
     bool profiling = false;
     hipEvent_t ev[kEvCount];  // timing events, recorded when profiling is on
@@ -933,6 +962,7 @@ extern "C" int orbx_create(const orbx_params* params, orbx_ctx** out) {
                            reinterpret_cast<const void*>(k_bow_vectors)})
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds) != hipSuccess)
             return fail(ORBX_E_HIP);
+    if ((rc = scratch_address(params->device_id, &c->scratch, &c->last_hip))) return fail(rc);
     {
         std::vector<uint32_t> tab((size_t)kDescTabVec * 64 * 4);
         build_describe_lane_table(kPattern, tab.data());
@@ -1104,6 +1134,37 @@ extern "C" int orbx_stereo_match_batch_device(orbx_ctx* c, int n_pairs, const or
     // pair p = images (2p, 2p + 1) of the last batch; their results are 2 * kp_cap keypoints apart
     rc = run_stereo(c, c, n_pairs, 0, 1, 2, d_kps, d_kps + kp_cap, d_desc, d_desc + (size_t)kp_cap * 32, d_n, d_n + 1,
                         2 * (int64_t)kp_cap, 2, kp_cap, mb, mbf, d_u_right, d_depth, scr);
+    if (rc) return rc;
+    if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_stereo_match_batch_device_noalloc(orbx_ctx* c, int n_pairs, const orbx_kp* d_kps, int kp_cap,
+                                                      const uint8_t* d_desc, const int32_t* d_n, float mb, float mbf,
+                                                      float* d_u_right, float* d_depth, int sync) {
+    if (!c || !d_kps || !d_desc || !d_n || !d_u_right || !d_depth || n_pairs < 1 || kp_cap < 1) return ORBX_E_INVALID;
+    if (!(mb > 0.0f) || !(mbf > 0.0f)) return ORBX_E_INVALID;
+    if (!c->have_last) return ORBX_E_STATE;
+    if (2 * n_pairs > c->B.nframes || kp_cap > 16384) return ORBX_E_CAPACITY;
+    const int rows = c->B.lv[0].h;
+    if (rows > 16383) return ORBX_E_CAPACITY;
+    // the per-pair scratch of the three kernels, carved out of the fixed array; sizes beyond it are refused
+    const size_t rows_b = align_up((size_t)n_pairs * (rows + 1) * 4, 256);
+    const size_t meta_b = align_up((size_t)n_pairs * kp_cap * sizeof(StereoMeta), 256);
+    const size_t wmax_b = align_up((size_t)n_pairs * 4, 256);
+    const size_t sad_b = (size_t)n_pairs * kp_cap * 4;
+    if (rows_b + meta_b + wmax_b + sad_b > kScratchBytes) return ORBX_E_CAPACITY;
+    HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    int rc = join(c);  // stream waits only: nothing is allocated on this path
+    if (rc) return rc;
+    uint8_t* base = c->scratch;  // the address hipGetSymbolAddress gave for this device, not the array's name
+    StereoScratch scr;
+    scr.row_start = (uint32_t*)base;
+    scr.meta = (StereoMeta*)(base + rows_b);
+    scr.wmax = (int32_t*)(base + rows_b + meta_b);
+    scr.sad = (int32_t*)(base + rows_b + meta_b + wmax_b);
+    rc = run_stereo(c, c, n_pairs, 0, 1, 2, d_kps, d_kps + kp_cap, d_desc, d_desc + (size_t)kp_cap * 32, d_n, d_n + 1,
+                    2 * (int64_t)kp_cap, 2, kp_cap, mb, mbf, d_u_right, d_depth, scr);
     if (rc) return rc;
     if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     return ORBX_OK;
