@@ -112,6 +112,21 @@ def load_library():
     return L
 
 
+def source_hash():
+    """sha256 over the kernel and launcher sources of the library (orb_slam2_amd/csrc, include/orbx.h).  Counter
+    summaries under profiles/ carry it, so that numbers collected on other code are recognised as stale."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.h*")) + glob.glob(os.path.join(_HERE, "csrc", "*.cpp")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "orbx.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _check(rc, ctx=None):
     if rc != 0:
         L = load_library()

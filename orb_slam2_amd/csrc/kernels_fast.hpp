@@ -132,15 +132,16 @@ struct FastShared {  // small per-workgroup state in static LDS
     int th[kFastTileCells];
 };
 
-// Full segment-test half score of the queued pixels in [q_lo, q_hi): ring darker than the centre
-// (DARK_RING = true, a "bright" corner) or ring brighter (evaluated as ring - centre).
+// Full segment-test half score of the 64 queued pixels [q0, q0 + 64) below q_hi, by one wave: ring
+// darker than the centre (BRIGHT = true, a "bright" corner) or ring brighter (evaluated as
+// ring - centre).
 template <bool BRIGHT, bool RETRY>
-__device__ __forceinline__ void fast_score_range(const uint8_t* s_tile, uint8_t* s_score, const uint16_t* s_queue,
-                                                 FastShared* sh, int q_lo, int q_hi, int TP, int SP, int wd, int nc,
-                                                 float inv_wcell, int thr, uint16_t* s_corner_top, int corner_room) {
+__device__ __forceinline__ void fast_score_wave(const uint8_t* s_tile, uint8_t* s_score, const uint16_t* s_queue,
+                                                FastShared* sh, int q0, int q_hi, int TP, int SP, int wd, int nc,
+                                                float inv_wcell, int thr, uint16_t* s_corner_top, int corner_room) {
     const int lane = threadIdx.x & 63;
-    for (int q0 = q_lo; q0 < q_hi; q0 += 256) {
-        const int q = q0 + (int)threadIdx.x;
+    {
+        const int q = q0 + lane;
         bool hit = false;
         int ke = 0;
         if (q < q_hi) {
@@ -380,9 +381,20 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
         return;
     }
     // ---- 2. full score of the queued pixels ----
+    // The two ends are cut into runs of 64 entries and the runs dealt to the four waves, so that a wave
+    // never idles through a pass over the other end: polarity is uniform per wave, not per workgroup.
     const int corner_room = max(0, min(k_cap, k_cap - kept_before));
-    fast_score_range<true, RETRY>(s_tile, s_score, s_queue, sh, 0, qf, TP, SP, wd, nc, inv_wcell, thr, s_keptl + k_cap - 1, corner_room);
-    fast_score_range<false, RETRY>(s_tile, s_score, s_queue, sh, q_cap - qb, q_cap, TP, SP, wd, nc, inv_wcell, thr, s_keptl + k_cap - 1, corner_room);
+    {
+        const int runs_f = (qf + 63) >> 6, runs = runs_f + ((qb + 63) >> 6);
+        for (int t = tid >> 6; t < runs; t += 4) {
+            if (t < runs_f)
+                fast_score_wave<true, RETRY>(s_tile, s_score, s_queue, sh, 64 * t, qf, TP, SP, wd, nc, inv_wcell, thr,
+                                             s_keptl + k_cap - 1, corner_room);
+            else
+                fast_score_wave<false, RETRY>(s_tile, s_score, s_queue, sh, q_cap - qb + 64 * (t - runs_f), q_cap, TP, SP, wd,
+                                              nc, inv_wcell, thr, s_keptl + k_cap - 1, corner_room);
+        }
+    }
     __syncthreads();
     ORBX_STAMP(B, stamp_base + 1, t0);
     // ---- 3. non-max suppression; survivors are listed and counted per cell ----
@@ -490,7 +502,7 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
 //  is its rank among the listed survivors (the list key is cell | row | column).
 __global__ __launch_bounds__(256) void k_fast_tiles(BatchDev B, const TileDesc* __restrict__ tiles,
                                                     uint32_t* __restrict__ cand, uint32_t* __restrict__ ccount,
-                                                    int tile_bytes, int plane_bytes, int queue_bytes) {
+                                                    int tile_bytes, int plane_bytes, int queue_bytes, int frame_major) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
     __shared__ FastShared sh;
 
@@ -500,9 +512,14 @@ __global__ __launch_bounds__(256) void k_fast_tiles(BatchDev B, const TileDesc* 
     uint16_t* s_keptl = reinterpret_cast<uint16_t*>(s_score + plane_bytes + queue_bytes);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const TileDesc td = tiles[blockIdx.x];
+    // grid = (tiles, frames), or (frames of a group of 8, tiles, groups) when the frames are dealt over
+    // the XCDs (workgroups go to the XCDs round-robin in x-fastest order: all tiles of a frame then meet in one L2)
+    const int tile_i = frame_major ? blockIdx.y : blockIdx.x;
+    const int frame = frame_major ? blockIdx.z * gridDim.x + blockIdx.x : blockIdx.y;
+    if (frame >= B.nframes) return;
+    const TileDesc td = tiles[tile_i];
     const LevelDev& L = B.lv[td.level];
-    const uint8_t* img = L.img + (uint64_t)blockIdx.y * L.plane;
+    const uint8_t* img = L.img + (uint64_t)frame * L.plane;
     const int wd = td.wd, hd = td.hd, nc = td.nc, w_cell = td.w_cell;
     const int TP = fast_tile_pitch(wd);
     const int SP = fast_plane_pitch(wd, nc);
@@ -566,7 +583,7 @@ __global__ __launch_bounds__(256) void k_fast_tiles(BatchDev B, const TileDesc* 
 #ifdef ORBX_STAMPS
     t0 = __builtin_amdgcn_s_memtime();
 #endif
-    const uint64_t slot0 = (uint64_t)blockIdx.y * B.total_cells + td.slot0;
+    const uint64_t slot0 = (uint64_t)frame * B.total_cells + td.slot0;
     const int nk = sh.n_kept;
     if (nk <= 256 && nk <= k_cap) {
         // rank among the listed survivors = position in (cell, row, column) order

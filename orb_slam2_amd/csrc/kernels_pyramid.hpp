@@ -265,7 +265,9 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // column whose 7-tap window leaves the image (columns [0,4) and the last 3..6) are not stored by
 // streaming lanes (their store offset is pushed out of the buffer's range); "edge" blocks compute
 // those columns through a small LDS tile of row sums.
-// grid = (B.blur_first[nlevels], frames), block = 256.
+// grid = (B.blur_first[nlevels], frames), block = 256; or, frame_major, (frames of a group of 8,
+// B.blur_first[nlevels], groups): workgroups go to the XCDs round-robin in x-fastest order, so the
+// blocks of a frame, which share halo rows and neighbour columns, then meet in one L2.
 constexpr int kBlurRows = 32;
 constexpr int kBlurPF = 8;
 constexpr int kBlurEdgeRows = 128;  // output rows per edge block
@@ -293,14 +295,17 @@ __host__ __device__ inline int blur_main_blocks(int w, int h) {
 }
 __host__ __device__ inline int blur_edge_blocks(int h) { return (h + kBlurEdgeRows - 1) / kBlurEdgeRows; }
 
-__global__ __launch_bounds__(256) void k_blur7_all(BatchDev B) {
+__global__ __launch_bounds__(256) void k_blur7_all(BatchDev B, int frame_major) {
+    const int blk_all = frame_major ? blockIdx.y : blockIdx.x;
+    const int frame = frame_major ? blockIdx.z * gridDim.x + blockIdx.x : blockIdx.y;
+    if (frame >= B.nframes) return;
     int level = 0;
-    while (level + 1 < B.nlevels && (int)blockIdx.x >= B.blur_first[level + 1]) ++level;
+    while (level + 1 < B.nlevels && blk_all >= B.blur_first[level + 1]) ++level;
     const LevelDev& L = B.lv[level];
-    const int blk = blockIdx.x - B.blur_first[level];
+    const int blk = blk_all - B.blur_first[level];
     const int w = L.w, h = L.h, spitch = L.pitch, dpitch = L.bpitch;
-    const uint8_t* S8 = L.img + (uint64_t)blockIdx.y * L.plane;
-    uint8_t* D8 = L.blur + (uint64_t)blockIdx.y * L.bplane;
+    const uint8_t* S8 = L.img + (uint64_t)frame * L.plane;
+    uint8_t* D8 = L.blur + (uint64_t)frame * L.bplane;
     const int tid = threadIdx.x;
     // streaming lanes store dwords x0 in [4, last_full]; edge blocks own [0,4) and [xs, w)
     const int last_full = ((w - 7) >> 2) << 2;

@@ -498,11 +498,18 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     };
     int rc;
     const int n_tiles = (int)c->tiles.size(), n_tiles0 = c->tiles_level0;
+    const bool blur_fm = n >= 8;  // as for the FAST tiles: a frame's blocks on one XCD
+    const dim3 blur_grid = blur_fm ? dim3(8, (unsigned)B.blur_first[L], (unsigned)((n + 7) / 8)) : dim3((unsigned)B.blur_first[L], n);
     auto launch_fast = [&](int first, int count) {
-        if (count > 0)
-            hipLaunchKernelGGL(k_fast_tiles, dim3((unsigned)count, n), dim3(256), c->fast_lds, st, B,
+        if (count > 0) {
+            // batches of 8 frames or more: the frames of a group of 8 in grid x, so that each XCD gets
+            // whole frames (neighbouring tiles share halo rows: 1.67 GB -> 0.72 GB fetched per 512 frames)
+            const bool fm = n >= 8;
+            const dim3 grid = fm ? dim3(8, (unsigned)count, (unsigned)((n + 7) / 8)) : dim3((unsigned)count, n);
+            hipLaunchKernelGGL(k_fast_tiles, grid, dim3(256), c->fast_lds, st, B,
                                (const TileDesc*)c->d_tiles.p + first, (uint32_t*)c->d_cand.p, (uint32_t*)c->d_ccount.p,
-                               c->fast_tile_bytes, c->fast_plane_bytes, c->fast_queue_bytes);
+                               c->fast_tile_bytes, c->fast_plane_bytes, c->fast_queue_bytes, fm ? 1 : 0);
+        }
     };
     if (overlap) {
         // level 0 and the arenas are ready when the main stream gets here
@@ -556,7 +563,7 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
         HIP_TRY(c, hipEventRecord(c->ev_fast_done, st));
         HIP_TRY(c, hipStreamWaitEvent(aux, c->ev_fast_done, 0));
         if ((rc = mark(kEvBlur0, aux))) return rc;
-        hipLaunchKernelGGL(k_blur7_all, dim3(B.blur_first[L], n), dim3(256), 0, aux, B);
+        hipLaunchKernelGGL(k_blur7_all, blur_grid, dim3(256), 0, aux, B, blur_fm ? 1 : 0);
         if ((rc = mark(kEvBlur1, aux))) return rc;
         HIP_TRY(c, hipEventRecord(c->ev_blur_done, aux));
     }
@@ -577,7 +584,7 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
         HIP_TRY(c, hipStreamWaitEvent(sd, c->ev_blur_done, 0));
     } else {
         if ((rc = mark(kEvBlur0, st))) return rc;
-        hipLaunchKernelGGL(k_blur7_all, dim3(B.blur_first[L], n), dim3(256), 0, st, B);
+        hipLaunchKernelGGL(k_blur7_all, blur_grid, dim3(256), 0, st, B, blur_fm ? 1 : 0);
         if ((rc = mark(kEvBlur1, st))) return rc;
     }
     // stage 4: orientation + descriptors + output assembly

@@ -40,15 +40,15 @@ def build(force=False):
     return _LIB_PATH
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(_LIB_PATH):
+def lib(path=None):
+    """The oracle library: the committed build, or another build of the same source at `path`."""
+    if path not in _libs:
+        if path is None and not os.path.exists(_LIB_PATH):
             build()
-        L = C.CDLL(_LIB_PATH)
+        L = C.CDLL(path or _LIB_PATH)
         u8p = C.POINTER(C.c_uint8)
         L.orc_params_init.argtypes = [C.POINTER(OrcParams), C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
         L.orc_level_size.argtypes = [C.POINTER(OrcParams), C.c_int, C.c_int, C.c_int,
@@ -105,8 +105,8 @@ def lib():
                                         C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_voc_transform.restype = None
         _ = u8p
-        _lib = L
-    return _lib
+        _libs[path] = L
+    return _libs[path]
 
 
 def _ptr(a):
@@ -253,62 +253,63 @@ def stereo_match(left, right, mb, mbf):
 class Oracle:
     """Whole-path CPU extractor with access to every intermediate."""
 
-    def __init__(self, nfeatures, scale_factor, nlevels, ini_th=20, min_th=7):
-        self._c = lib().orc_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+    def __init__(self, nfeatures, scale_factor, nlevels, ini_th=20, min_th=7, lib_path=None):
+        self._L = lib(lib_path)
+        self._c = self._L.orc_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
         assert self._c
         self.nlevels = nlevels
 
     def __del__(self):
         if getattr(self, "_c", None):
-            lib().orc_destroy(self._c)
+            self._L.orc_destroy(self._c)
             self._c = None
 
     @property
     def params(self):
-        return lib().orc_get_params(self._c).contents
+        return self._L.orc_get_params(self._c).contents
 
     def extract(self, img):
         img = np.asarray(img)
         assert img.dtype == np.uint8 and img.ndim == 2 and img.strides[1] == 1
-        n = lib().orc_extract(self._c, _ptr(img), img.shape[1], img.shape[0], img.strides[0])
+        n = self._L.orc_extract(self._c, _ptr(img), img.shape[1], img.shape[0], img.strides[0])
         assert n >= 0, n
         kps = np.zeros(n, dtype=KP_DTYPE)
         desc = np.zeros((n, 32), dtype=np.uint8)
-        lib().orc_get_keypoints(self._c, _ptr(kps))
-        lib().orc_get_descriptors(self._c, _ptr(desc))
+        self._L.orc_get_keypoints(self._c, _ptr(kps))
+        self._L.orc_get_descriptors(self._c, _ptr(desc))
         return kps, desc
 
     def level_dims(self, l):
         w, h = C.c_int(), C.c_int()
-        lib().orc_get_level_dims(self._c, l, C.byref(w), C.byref(h))
+        self._L.orc_get_level_dims(self._c, l, C.byref(w), C.byref(h))
         return w.value, h.value
 
     def level(self, l):
         w, h = self.level_dims(l)
         a = np.empty((h, w), dtype=np.uint8)
-        lib().orc_get_level(self._c, l, _ptr(a))
+        self._L.orc_get_level(self._c, l, _ptr(a))
         return a
 
     def blurred(self, l):
         w, h = self.level_dims(l)
         a = np.empty((h, w), dtype=np.uint8)
-        lib().orc_get_blurred(self._c, l, _ptr(a))
+        self._L.orc_get_blurred(self._c, l, _ptr(a))
         return a
 
     def padded_level(self, l):
         w, h = self.level_dims(l)
         a = np.empty((h + 38, w + 38), dtype=np.uint8)
-        lib().orc_get_level_padded(self._c, l, _ptr(a))
+        self._L.orc_get_level_padded(self._c, l, _ptr(a))
         return a
 
     def candidates(self, l):
-        n = lib().orc_get_num_candidates(self._c, l)
+        n = self._L.orc_get_num_candidates(self._c, l)
         a = np.zeros(n, dtype=CAND_DTYPE)
-        lib().orc_get_candidates(self._c, l, _ptr(a))
+        self._L.orc_get_candidates(self._c, l, _ptr(a))
         return a
 
     def level_keypoint_count(self, l):
-        return lib().orc_get_num_level_keypoints(self._c, l)
+        return self._L.orc_get_num_level_keypoints(self._c, l)
 
 
 def search_window(xy, octave, desc, u_right, taken, cell_start, cell_idx, min_x, min_y, inv_w, inv_h, u, v, radius,

@@ -12,8 +12,12 @@ usage: traffic_summary.py <dir with rd/ and wr/> <out.json>
 """
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from orb_slam2_amd import source_hash  # noqa: E402
 
 
 def per_launch(path):
@@ -42,10 +46,11 @@ def main():
         write = wr.get(k, (0.0, 0))[0] * wr.get(k, (0.0, 0))[1] * 1024.0 / steps
         res[k.replace("orbx::", "")] = {"launches_sampled": rd[k][1], "fetch_bytes": fetch, "write_bytes": write,
                                         "traffic_bytes": fetch + write}
+    res["_source_sha256"] = source_hash()
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
     for k, v in res.items():
-        if k != "_note":
+        if not k.startswith("_"):
             print("%-20s launches %3d  fetch %8.1f MB  write %8.1f MB" % (k, v["launches_sampled"], v["fetch_bytes"] / 1e6,
                                                                         v["write_bytes"] / 1e6))
 

@@ -7,8 +7,12 @@ usage: valu_summary.py <out.json> <pmc_counter_collection.csv> [more csv ...]
 """
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from orb_slam2_amd import source_hash  # noqa: E402
 
 WANT = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_WAVES")
 
@@ -31,6 +35,7 @@ def main():
             res[name][ctr] = v / steps
     res["_note"] = ("wave instructions per extraction step (512 frames) of `bench.py --steps 2 --warmup 1`, summed over a "
                     "kernel's launches of the step; one rocprofv3 --pmc pass per counter group")
+    res["_source_sha256"] = source_hash()
     with open(out, "w") as f:
         json.dump(res, f, indent=1, sort_keys=True)
     for k in sorted(res):
