@@ -406,8 +406,20 @@ void divide_node(const Node& p, const orc_cand* c, Node& n1, Node& n2, Node& n3,
 
 }  // namespace
 
-extern "C" int orc_distribute_octree(const orc_cand* cands, int n, int minX, int maxX, int minY,
-                                     int maxY, int N, int32_t* out_idx, int cap) {
+// Tie order among equal-size nodes in the sort at :770.  0 = decision D2 (the pinned order, the
+// only one the product is compared with); 1 = the reverse; 2 = a fixed pseudo-random order.  The
+// alternatives exist to measure how much of the output hangs on the tie-break
+// (tools/tolerance_study.py): the reference orders such nodes by their heap addresses.
+static int g_d2_mode = 0;
+extern "C" void orc_set_d2_mode(int mode) { g_d2_mode = mode; }
+
+// d2_sensitive (may be null) receives 1 when the one-at-a-time phase stopped (:816) with the next
+// node in line as large as the last one split: the pinned tie-break D2 then chose which of several
+// equal-size nodes was split, and a build of the reference with another heap layout may retain a
+// different set; 0 when the retained SET cannot depend on the tie-break.
+extern "C" int orc_distribute_octree_ex(const orc_cand* cands, int n, int minX, int maxX, int minY,
+                                        int maxY, int N, int32_t* out_idx, int cap, int* d2_sensitive) {
+    if (d2_sensitive) *d2_sensitive = 0;
     const int nIni = (int)std::round((float)(maxX - minX) / (maxY - minY));  // :576
     if (nIni < 1) return -1;  // undefined behaviour in the reference (tall images)
     const float hX = (float)(maxX - minX) / nIni;
@@ -442,8 +454,15 @@ extern "C" int orc_distribute_octree(const orc_cand* cands, int n, int minX, int
     bool bFinish = false;
     typedef std::pair<int, Node*> SizeNode;
     // decision D2: the reference compares (size, pointer); pointers are replaced by seq
-    auto less_d2 = [](const SizeNode& a, const SizeNode& b) {
+    const int d2_mode = g_d2_mode;
+    auto less_d2 = [d2_mode](const SizeNode& a, const SizeNode& b) {
         if (a.first != b.first) return a.first < b.first;
+        if (d2_mode == 1) return a.second->seq > b.second->seq;
+        if (d2_mode == 2) {
+            const unsigned long ha = (unsigned long)a.second->seq * 2654435761ul % 1000003ul;
+            const unsigned long hb = (unsigned long)b.second->seq * 2654435761ul % 1000003ul;
+            if (ha != hb) return ha < hb;
+        }
         return a.second->seq < b.second->seq;
     };
     std::vector<SizeNode> vSizeAndPointerToNode;
@@ -492,7 +511,10 @@ extern "C" int orc_distribute_octree(const orc_cand* cands, int n, int minX, int
                     push_child(n3, true, nullptr);
                     push_child(n4, true, nullptr);
                     lNodes.erase(vPrev[j].second->lit);
-                    if ((int)lNodes.size() >= N) break;
+                    if ((int)lNodes.size() >= N) {
+                        if (d2_sensitive && j > 0 && vPrev[j - 1].first == vPrev[j].first) *d2_sensitive = 1;
+                        break;
+                    }
                 }
                 if ((int)lNodes.size() >= N || (int)lNodes.size() == prevSize) bFinish = true;
             }
@@ -513,6 +535,11 @@ extern "C" int orc_distribute_octree(const orc_cand* cands, int n, int minX, int
         m++;
     }
     return m;
+}
+
+extern "C" int orc_distribute_octree(const orc_cand* cands, int n, int minX, int maxX, int minY,
+                                     int maxY, int N, int32_t* out_idx, int cap) {
+    return orc_distribute_octree_ex(cands, n, minX, maxX, minY, maxY, N, out_idx, cap, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -639,6 +666,54 @@ extern "C" void orc_descriptor(const uint8_t* blurred, int stride, int x, int y,
     }
 }
 
+// The descriptor under the alternatives to decisions D1 and D6, for measuring how far a real
+// build of the reference can be from the pinned form (tools/tolerance_study.py):
+//   rotation 0: the FMA form (D1, the author's -march=native build)
+//            1: :123-125 as written, every product and sum rounded (a build without FMA contraction)
+//   sincos   0: the pinned a = cos, b = sin (D6)
+//            1: this host's libm cosf / sinf (:118)
+//            2..5: the pinned values with a + 1 ulp, a - 1 ulp, b + 1 ulp, b - 1 ulp (what a libm
+//               within one unit in the last place can return)
+extern "C" void orc_descriptor_variant(const uint8_t* blurred, int stride, int x, int y, float angle_deg,
+                                       int rotation, int sincos, uint8_t desc[32]) {
+    float a, b;
+    if (sincos == 1) {
+        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+        const float angle = angle_deg * factorPI;
+        a = cosf(angle);
+        b = sinf(angle);
+    } else {
+        orc_sincos_deg(angle_deg, &a, &b);
+        if (sincos == 2) a = std::nextafterf(a, 2.f);
+        if (sincos == 3) a = std::nextafterf(a, -2.f);
+        if (sincos == 4) b = std::nextafterf(b, 2.f);
+        if (sincos == 5) b = std::nextafterf(b, -2.f);
+    }
+    const uint8_t* center = blurred + (size_t)y * stride + x;
+    const int8_t* pat = kPattern;
+    auto get = [&](int idx) -> int {
+        const float px = (float)pat[2 * idx], py = (float)pat[2 * idx + 1];
+        int row, col;
+        if (rotation == 0) {
+            row = cv_roundf(std::fmaf(px, b, py * a));
+            col = cv_roundf(std::fmaf(px, a, -(py * b)));
+        } else {
+            volatile float xb = px * b, ya = py * a, xa = px * a, yb = py * b;  // each product rounded to float32
+            row = cv_roundf(xb + ya);
+            col = cv_roundf(xa - yb);
+        }
+        return center[row * stride + col];
+    };
+    for (int i = 0; i < 32; ++i, pat += 32) {
+        int val = 0;
+        for (int j = 0; j < 8; j++) {
+            int t0 = get(2 * j), t1 = get(2 * j + 1);
+            val |= (t0 < t1) << j;
+        }
+        desc[i] = (uint8_t)val;
+    }
+}
+
 extern "C" const int8_t* orc_pattern(void) { return kPattern; }
 
 // ---------------------------------------------------------------------------------------
@@ -650,6 +725,7 @@ struct orc_ctx {
     std::vector<uint8_t> level[ORC_MAX_LEVELS], blurred[ORC_MAX_LEVELS];
     std::vector<orc_cand> cands[ORC_MAX_LEVELS];
     int nkp_level[ORC_MAX_LEVELS];
+    int d2_sensitive[ORC_MAX_LEVELS];
     std::vector<orc_kp> kps;
     std::vector<uint8_t> desc;
 };
@@ -699,9 +775,10 @@ extern "C" int orc_extract(orc_ctx* c, const uint8_t* img, int w, int h, int str
         cd.resize(n);
         std::vector<int32_t> keep((size_t)n + 4);
         int m = 0;
+        c->d2_sensitive[l] = 0;
         if (n > 0) {
-            m = orc_distribute_octree(cd.data(), n, minBorderX, maxBorderX, minBorderY, maxBorderY,
-                                      p.quota[l], keep.data(), (int)keep.size());
+            m = orc_distribute_octree_ex(cd.data(), n, minBorderX, maxBorderX, minBorderY, maxBorderY,
+                                         p.quota[l], keep.data(), (int)keep.size(), &c->d2_sensitive[l]);
             if (m < 0) return -3;
         }
         const int scaledPatchSize = (int)(PATCH_SIZE * p.scale[l]);  // :930
@@ -774,6 +851,7 @@ extern "C" void orc_get_candidates(const orc_ctx* c, int level, orc_cand* out) {
         std::memcpy(out, c->cands[level].data(), c->cands[level].size() * sizeof(orc_cand));
 }
 extern "C" int orc_get_num_level_keypoints(const orc_ctx* c, int level) { return c->nkp_level[level]; }
+extern "C" int orc_get_d2_sensitive(const orc_ctx* c, int level) { return c->d2_sensitive[level]; }
 
 // copyMakeBorder(..., 19,19,19,19, BORDER_REFLECT_101): :1239-1245
 extern "C" void orc_get_level_padded(const orc_ctx* c, int level, uint8_t* out) {

@@ -98,11 +98,19 @@ int orc_level_candidates(const uint8_t* img, int w, int h, int stride, int ini_t
 /* DistributeOctTree: writes indices (into cands) of retained points in list order */
 int orc_distribute_octree(const orc_cand* cands, int n, int minX, int maxX, int minY, int maxY,
                           int N, int32_t* out_idx, int cap);
+/* measurement only: tie order of equal-size nodes, 0 = decision D2 (default), 1 = reverse, 2 = pseudo-random */
+void orc_set_d2_mode(int mode);
+/* as above; *d2_sensitive = 1 when the retained set depends on the pinned tie-break D2 */
+int orc_distribute_octree_ex(const orc_cand* cands, int n, int minX, int maxX, int minY, int maxY,
+                             int N, int32_t* out_idx, int cap, int* d2_sensitive);
 float orc_fast_atan2(float y, float x);
 float orc_ic_angle(const uint8_t* img, int stride, int x, int y, const int* umax);
 void orc_sincos_deg(float angle_deg, float* cos_out, float* sin_out);
 void orc_descriptor(const uint8_t* blurred, int stride, int x, int y, float angle_deg,
                     uint8_t desc[32]);
+/* the descriptor under the alternatives to decisions D1 (rotation) and D6 (sincos), see the source */
+void orc_descriptor_variant(const uint8_t* blurred, int stride, int x, int y, float angle_deg,
+                            int rotation, int sincos, uint8_t desc[32]);
 const int8_t* orc_pattern(void); /* 1024 values */
 
 /* whole path */

@@ -311,3 +311,41 @@ def test_descriptor_vs_python(oracle):
             if vals[2 * k] < vals[2 * k + 1]:
                 exp[k // 8] |= 1 << (k % 8)
         assert (oracle.descriptor(img, 30, 30, ang) == exp).all()
+
+
+def test_measurement_variants_of_the_pinned_decisions(oracle):
+    """The hooks tools/tolerance_study.py measures with: the descriptor variant (0, 0) IS the pinned descriptor,
+    the other variants differ from it in few bits at most, and another quadtree tie order keeps the per-level
+    counts inside [N, N + 3] and is switched off again by mode 0."""
+    import ctypes as C
+    from orb_slam2_amd import synth
+    L = oracle.lib()
+    L.orc_descriptor_variant.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
+    L.orc_set_d2_mode.argtypes = [C.c_int]
+    L.orc_get_d2_sensitive.argtypes = [C.c_void_p, C.c_int]
+    img = synth.make_frame(640, 480, 1, 2)
+    orc = oracle.Oracle(1000, 1.2, 8, 20, 7)
+    kps, desc = orc.extract(img)
+    b0 = np.ascontiguousarray(orc.blurred(0))
+    tmp = np.zeros(32, np.uint8)
+    lvl0 = np.nonzero(kps["octave"] == 0)[0][:100]
+    for i in lvl0:
+        x, y, ang = int(kps["x"][i]), int(kps["y"][i]), float(kps["angle"][i])
+        L.orc_descriptor_variant(b0.ctypes.data, b0.shape[1], x, y, ang, 0, 0, tmp.ctypes.data)
+        assert (tmp == desc[i]).all()
+        for rot, sc in ((1, 0), (0, 1), (0, 2), (0, 5)):
+            L.orc_descriptor_variant(b0.ctypes.data, b0.shape[1], x, y, ang, rot, sc, tmp.ctypes.data)
+            assert np.unpackbits(tmp ^ desc[i]).sum() <= 4
+    quota = orc.params.quota
+    try:
+        for mode in (1, 2):
+            L.orc_set_d2_mode(mode)
+            k2, _ = orc.extract(img)
+            for l in range(8):
+                n = int((k2["octave"] == l).sum())
+                assert n == int((kps["octave"] == l).sum()) or quota[l] <= n <= quota[l] + 3
+    finally:
+        L.orc_set_d2_mode(0)
+    k3, d3 = orc.extract(img)
+    assert (k3 == kps).all() and (d3 == desc).all()
+    assert all(L.orc_get_d2_sensitive(orc._c, l) in (0, 1) for l in range(8))
