@@ -141,6 +141,7 @@ struct orbx_ctx {
     // diagnostic switches: read from the environment once, in orbx_create; orbx_set_debug_flag changes them
     bool dbg_no_overlap = false, dbg_resize_tiles = false, dbg_stereo_border = false, dbg_trace = false, dbg_no_graph = false;
     int dbg_pipe_chunk = 0;
+    bool dbg_aux_low_priority = false;
     // launch graph of the single-frame host path (captured once per image size, replayed by orbx_extract)
     hipGraphExec_t graph_exec = nullptr;
     int graph_w = -1, graph_h = -1, graph_cap = 0;
@@ -458,7 +459,13 @@ int ensure_aux_streams(orbx_ctx* c) {
     if (c->aux_made) return ORBX_OK;
     // All streams at the default priority: with low-priority streams a wait on one of them from a
     // default-priority stream stalled for tens of seconds (measured with the chunked host path).
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->st_aux, hipStreamNonBlocking));
+    if (c->dbg_aux_low_priority) {  // diagnostic: the configuration in which the chunked host path stalled
+        int least = 0, greatest = 0;
+        HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(c, hipStreamCreateWithPriority(&c->st_aux, hipStreamNonBlocking, least));
+    } else {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->st_aux, hipStreamNonBlocking));
+    }
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pyr_done, hipEventDisableTiming));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->st_desc, hipStreamNonBlocking));
@@ -953,6 +960,7 @@ extern "C" int orbx_create(const orbx_params* params, orbx_ctx** out) {
     c->dbg_stereo_border = std::getenv("ORBX_STEREO_BORDER_PATH") != nullptr;
     c->dbg_trace = std::getenv("ORBX_TRACE") != nullptr;
     c->dbg_no_graph = std::getenv("ORBX_NO_GRAPH") != nullptr;
+    c->dbg_aux_low_priority = std::getenv("ORBX_AUX_LOW_PRIORITY") != nullptr;
     if (const char* e = std::getenv("ORBX_PIPE_CHUNK")) c->dbg_pipe_chunk = std::max(0, std::atoi(e));
     int rc = ORBX_OK;
     auto fail = [&](int code) {
