@@ -85,11 +85,23 @@ __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(fast_u16x2, a), __builtin_bit_cast(fast_u16x2, b)));
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP adds (row shifts 1, 2, 4, 8 inside the rows of
+// 16 lanes, then the row broadcasts 15 and 31); lanes a shift does not reach add 0.
+__device__ __forceinline__ int wave_incl_scan(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+    return x;
+}
+
 constexpr int kFastMaxCell = 66;  // largest sub-image side: wCell <= 59, + 6, + 1
 
 // LDS carve-up of k_fast_tiles for one tile geometry (bytes).
 struct FastLds {
-    int tile, plane, queue, kept;
+    int tile, plane, queue, kept, verdict;
 };
 // Tile layout: LDS column of detection column u is u + 4, so u = 0 sits on a dword boundary and
 // the 3-pixel halo on its left occupies columns 1..3.  Four spare columns on the right keep the
@@ -100,12 +112,15 @@ __host__ __device__ inline int fast_plane_pitch(int wd, int nc) { return (wd + n
 // produce (about 15 %); a tile that overflows falls back to scoring every pixel.
 __host__ __device__ inline int fast_queue_cap(int wd, int hd) { return (((wd + 3) & ~3) * hd) / 2; }
 __host__ __device__ inline int fast_kept_cap(int wd, int hd) { return (((wd + 3) & ~3) * hd) / 8 + 64; }
+// Verdict plane of step 1: one byte per work item (a dword of four pixels), rows of a multiple of four items.
+__host__ __device__ inline int fast_verdict_pitch(int wd) { return (((wd + 3) >> 2) + 3) & ~3; }
 __host__ __device__ inline FastLds fast_lds_need(int wd, int hd, int nc) {
     FastLds n;
     n.tile = fast_tile_pitch(wd) * (hd + 6) + 16;
     n.plane = fast_plane_pitch(wd, nc) * (hd + 2);
     n.queue = fast_queue_cap(wd, hd) * 2;
     n.kept = fast_kept_cap(wd, hd) * 2;
+    n.verdict = fast_verdict_pitch(wd) * hd;
     return n;
 }
 
@@ -202,8 +217,8 @@ __device__ __forceinline__ void fast_score_wave(const uint8_t* s_tile, uint8_t* 
 // cell; RETRY = true: threshold minTh, only the cells whose th entry is >= 0.
 template <bool RETRY>
 __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_score, uint16_t* s_queue, uint16_t* s_keptl,
-                                          FastShared* sh, int TP, int SP, int wd, int hd, int nc, float inv_wcell,
-                                          int thr, int q_cap, int k_cap, const BatchDev& B, int stamp_base) {
+                                          uint8_t* s_verdict, FastShared* sh, int TP, int SP, int wd, int hd, int nc,
+                                          float inv_wcell, int thr, int q_cap, int k_cap, const BatchDev& B, int stamp_base) {
     const int tid = threadIdx.x, lane = tid & 63;
     unsigned long long t0 = 0;
 #ifdef ORBX_STAMPS
@@ -217,13 +232,16 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
     __syncthreads();
     // ---- 1. rejection test, four pixels per work item, two pixels per instruction ----
     // Any arc of 9 holds one pixel of each opposite pair, so a corner needs the two compass pairs
-    // (up/down, left/right) to each hold a pixel beyond the threshold on the same side.  The
+    // (up/down, left/right) and the two diagonal pairs ((+-2, +-2)) to each hold a pixel beyond the threshold
+    // on the same side.  (The diagonal pairs halve the survivors, 11.5 % -> 5.7 % of the pixels of a textured
+    // frame against 2.8 % corners, for a third more instructions in the test.)  The
     // dword's bytes are split into even and odd pixels as two 16-bit lanes; packed u16 min/max
     // combine the ring pixels of the pairs, and one biased 32-bit subtract per polarity against the
     // centre moves "beyond the threshold" into bit 15 of each lane.
-    // Pixels whose ring is darker go to the front of the queue, brighter ones to its back, so that
-    // step 2 runs each half of the score on a dense range.
-    const int ndwd = (wd + 3) >> 2, n_items = hd * ndwd;
+    // The eight verdicts of a work item (four pixels, two polarities) go to a byte plane; step 1b turns the
+    // plane into the queue.  (Appending to the queue here, with one ballot per verdict, cost as many vector
+    // instructions again as the test itself.)
+    const int ndwd = (wd + 3) >> 2, n_items = hd * ndwd, vp = fast_verdict_pitch(wd);
     const uint32_t k_thr = (uint32_t)(0x8000 - 1 - thr) * 0x00010001u;
     // (row, dword) of item tid, advanced by 256 items per iteration without divisions
     int v = (int)(((float)tid + 0.5f) * (1.0f / (float)ndwd));
@@ -231,8 +249,7 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
     const int dv = 256 / ndwd, dj = 256 - dv * ndwd;
     for (int i0 = 0; i0 < n_items; i0 += 256) {
         uint32_t pb[2], pd[2];  // [0]: bits 15/31 = pixels 0/2, [1]: pixels 1/3
-        // items past the end (last iteration only) test a row of the tile again; their hits are masked off
-        const uint64_t live = __ballot(v < hd);
+        // items past the end (last iteration only) test a row of the tile again; their verdicts are not stored
         {
             const uint8_t* pc = s_tile + __umul24((uint32_t)(min(v, hd - 1) + 3), (uint32_t)TP) + 4 * j + 4;
             const uint32_t Cd = *reinterpret_cast<const uint32_t*>(pc);
@@ -241,6 +258,14 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
             // pixels +3 / -3: aligned neighbour dwords shifted into place (unaligned LDS reads are slow)
             const uint32_t Rd = __builtin_amdgcn_alignbyte(*reinterpret_cast<const uint32_t*>(pc + 4), Cd, 3);
             const uint32_t Ld = __builtin_amdgcn_alignbyte(Cd, *reinterpret_cast<const uint32_t*>(pc - 4), 1);
+            // the two diagonal pairs (ring positions 2/10 and 6/14: pixels (+-2, +-2)) join the test: an arc of 9
+            // holds one pixel of each of them too
+            const uint32_t P2c = *reinterpret_cast<const uint32_t*>(pc + 2 * TP), P2p = *reinterpret_cast<const uint32_t*>(pc + 2 * TP - 4),
+                           P2n = *reinterpret_cast<const uint32_t*>(pc + 2 * TP + 4);
+            const uint32_t M2c = *reinterpret_cast<const uint32_t*>(pc - 2 * TP), M2p = *reinterpret_cast<const uint32_t*>(pc - 2 * TP - 4),
+                           M2n = *reinterpret_cast<const uint32_t*>(pc - 2 * TP + 4);
+            const uint32_t Dpp = __builtin_amdgcn_alignbyte(P2n, P2c, 2), Dmp = __builtin_amdgcn_alignbyte(P2c, P2p, 2);
+            const uint32_t Dpm = __builtin_amdgcn_alignbyte(M2n, M2c, 2), Dmm = __builtin_amdgcn_alignbyte(M2c, M2p, 2);
             uint32_t on[2] = {0x80008000u, 0x80008000u};
             if (RETRY) {
 #pragma unroll
@@ -260,8 +285,14 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
                 // ring darker on both pairs: centre - max(min(u,d), min(l,r)) > t; ring brighter:
                 // min(max(u,d), max(l,r)) - centre > t.  With k = 0x8000 - 1 - t added to the minuend the
                 // verdict is bit 15 of each lane, and no lane borrows from its neighbour.
-                const uint32_t hi = pk_max_u16(pk_min_u16(u, d), pk_min_u16(l, r));
-                const uint32_t lo = pk_min_u16(pk_max_u16(u, d), pk_max_u16(l, r));
+                uint32_t hi = pk_max_u16(pk_min_u16(u, d), pk_min_u16(l, r));
+                uint32_t lo = pk_min_u16(pk_max_u16(u, d), pk_max_u16(l, r));
+                {
+                    const uint32_t pp = __builtin_amdgcn_perm(0u, Dpp, sel), mm = __builtin_amdgcn_perm(0u, Dmm, sel);
+                    const uint32_t pm = __builtin_amdgcn_perm(0u, Dpm, sel), mp = __builtin_amdgcn_perm(0u, Dmp, sel);
+                    hi = pk_max_u16(hi, pk_max_u16(pk_min_u16(pp, mm), pk_min_u16(pm, mp)));
+                    lo = pk_min_u16(lo, pk_min_u16(pk_max_u16(pp, mm), pk_max_u16(pm, mp)));
+                }
                 pb[h2] = (c + k_thr) - hi;  // only bits 15 and 31 are read
                 pd[h2] = (lo + k_thr) - c;
                 if (RETRY) {
@@ -270,67 +301,16 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
                 }
             }
         }
-        const int e0 = (v << 8) + 4 * j;
-        // masks of the passing pixels, [side][pixel of the dword]: bit 15 of the even/odd word is the
-        // sign of its low half, bit 31 the sign of the word, so one compare gives each wave-wide mask.
-        // The compares run with the lanes past the end switched off, which leaves their mask bits zero.
-        uint64_t m[2][4];
+        // Verdict byte of the work item: bit 2p + 1 = ring darker, bit 2p = ring brighter for pixel p of the dword.
+        // One v_perm_b32 per side gathers the four sign bytes in pixel order; the shifts fold the bit pairs of the
+        // four bytes into one.  Items past the end (last iteration only) store nothing.
         {
-            uint64_t saved;
-            asm volatile(
-                "s_and_saveexec_b64 %[sv], %[live]\n\t"
-                "v_cmp_gt_i16 %[b0], 0, %[pbe]\n\t"
-                "v_cmp_gt_i16 %[b1], 0, %[pbo]\n\t"
-                "v_cmp_gt_i32 %[b2], 0, %[pbe]\n\t"
-                "v_cmp_gt_i32 %[b3], 0, %[pbo]\n\t"
-                "v_cmp_gt_i16 %[d0], 0, %[pde]\n\t"
-                "v_cmp_gt_i16 %[d1], 0, %[pdo]\n\t"
-                "v_cmp_gt_i32 %[d2], 0, %[pde]\n\t"
-                "v_cmp_gt_i32 %[d3], 0, %[pdo]\n\t"
-                "s_mov_b64 exec, %[sv]"
-                : [sv] "=&s"(saved), [b0] "=&s"(m[0][0]), [b1] "=&s"(m[0][1]), [b2] "=&s"(m[0][2]), [b3] "=&s"(m[0][3]),
-                  [d0] "=&s"(m[1][0]), [d1] "=&s"(m[1][1]), [d2] "=&s"(m[1][2]), [d3] "=&s"(m[1][3])
-                : [live] "s"(live), [pbe] "v"(pb[0]), [pbo] "v"(pb[1]), [pde] "v"(pd[0]), [pdo] "v"(pd[1]));
-        }
-        int tot[2];
-#pragma unroll
-        for (int side = 0; side < 2; ++side)
-            tot[side] = __popcll(m[side][0]) + __popcll(m[side][1]) + __popcll(m[side][2]) + __popcll(m[side][3]);
-        if (tot[0] | tot[1]) {
-            // one counter update reserves both ends: front count in the low half, back count in the high
-            // half (issued as a plain LDS instruction: lane 0 alone adds for the wave)
-            int base = 0;
-            if (lane == 0) {
-                uint32_t got;
-                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
-                             : "=v"(got)
-                             : "v"((uint32_t)(uintptr_t)&sh->q_fb), "v"((uint32_t)(tot[0] | (tot[1] << 16)))
-                             : "memory");
-                base = (int)got;
-            }
-            base = __builtin_amdgcn_readfirstlane(base);
-            const uint32_t eb[4] = {(uint32_t)e0, (uint32_t)e0 + 1u, (uint32_t)e0 + 2u, (uint32_t)e0 + 3u};
-            // a reservation that does not fit is skipped as a whole; the overflow is detected after the loop
-#pragma unroll
-            for (int side = 0; side < 2; ++side) {
-                int at = side ? (int)((uint32_t)base >> 16) : (base & 0xFFFF);
-                if (at + tot[side] > q_cap) continue;
-                // front: slots at, at+1, ... upwards from 0; back: q_cap-1-at, ... downwards.  The slot of a
-                // lane is the wave-uniform start plus (front) or minus (back) its rank among the hits.
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const uint64_t mm = m[side][b];
-                    if (__builtin_amdgcn_inverse_ballot_w64(mm)) {
-                        const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-                        if (side) {
-                            (s_queue + (q_cap - 1 - at))[-r] = (uint16_t)eb[b];
-                        } else {
-                            (s_queue + at)[r] = (uint16_t)eb[b];
-                        }
-                    }
-                    at += __popcll(mm);
-                }
-            }
+            const uint32_t Bm = __builtin_amdgcn_perm(pb[1], pb[0], 0x07030501u) & 0x80808080u;
+            const uint32_t Dm = __builtin_amdgcn_perm(pd[1], pd[0], 0x07030501u);
+            uint32_t t = (((Dm >> 1) & 0x40404040u) | Bm) >> 6;
+            t |= t >> 6;
+            t |= t >> 12;
+            if (v < hd) s_verdict[__umul24((uint32_t)v, (uint32_t)vp) + j] = (uint8_t)t;
         }
         v += dv;
         j += dj;
@@ -340,7 +320,67 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
         }
     }
     __syncthreads();
+    // ---- 1b. the verdict plane becomes the two-ended queue ----
+    // A thread takes the verdicts of four neighbouring work items (16 pixels of one row) as one dword, the
+    // wave's prefix sums of the two counts (ring darker | ring brighter << 16, DPP scan) and ONE LDS add per
+    // wave give every lane its first slot at each end, and the lane then writes its hits one per iteration.
+    // Pixels whose ring is darker go to the front of the queue, brighter ones to its back, so that
+    // step 2 runs each half of the score on a dense range.  A wave whose reservation does not fit skips
+    // its writes; the overflow is detected after the pass.
+    {
+        const int vp4 = vp >> 2, n_groups = hd * vp4;
+        const float inv_vp4 = 1.0f / (float)vp4;
+        const uint32_t* s_verdict32 = reinterpret_cast<const uint32_t*>(s_verdict);
+        for (int g0 = 0; g0 < n_groups; g0 += 256) {
+            const int g = g0 + tid;
+            uint32_t w = 0;
+            int ebase = 0;
+            if (g < n_groups) {
+                w = s_verdict32[g];
+                const int vg = (int)(((float)g + 0.5f) * inv_vp4);
+                ebase = (vg << 8) + 16 * (g - vg * vp4);
+            }
+            uint32_t wf = w & 0xAAAAAAAAu, wb = w & 0x55555555u;  // front: ring darker; back: ring brighter
+            const int cnt = __popc(wf) | (__popc(wb) << 16);
+            const int incl = wave_incl_scan(cnt);
+            const int tot = __builtin_amdgcn_readlane(incl, 63);
+            if (tot == 0) continue;  // wave-uniform
+            int base = 0;
+            if (lane == 0) {
+                uint32_t got;
+                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                             : "=v"(got)
+                             : "v"((uint32_t)(uintptr_t)&sh->q_fb), "v"((uint32_t)tot)
+                             : "memory");
+                base = (int)got;
+            }
+            base = __builtin_amdgcn_readfirstlane(base);
+            const int excl = incl - cnt;
+            if ((base & 0xFFFF) + (tot & 0xFFFF) > q_cap) wf = 0;
+            if ((int)((uint32_t)base >> 16) + (int)((uint32_t)tot >> 16) > q_cap) wb = 0;
+            uint16_t* qf_p = s_queue + (base & 0xFFFF) + (excl & 0xFFFF);                                   // upwards
+            uint16_t* qb_p = s_queue + (q_cap - 1) - ((int)((uint32_t)base >> 16) + (int)((uint32_t)excl >> 16));  // downwards
+            while (__builtin_amdgcn_ballot_w64(wf != 0)) {
+                if (wf) {
+                    const int k = __builtin_ctz(wf);
+                    *qf_p++ = (uint16_t)(ebase + (k >> 1));
+                    wf &= wf - 1;
+                }
+            }
+            while (__builtin_amdgcn_ballot_w64(wb != 0)) {
+                if (wb) {
+                    const int k = __builtin_ctz(wb);
+                    *qb_p-- = (uint16_t)(ebase + (k >> 1));
+                    wb &= wb - 1;
+                }
+            }
+        }
+    }
+    __syncthreads();
     ORBX_STAMP(B, stamp_base + 0, t0);
+#ifdef ORBX_FAST_STOP
+    if (ORBX_FAST_STOP == 2) return;
+#endif
     const int qf = sh->q_fb & 0xFFFF, qb = (int)((uint32_t)sh->q_fb >> 16);
     if (qf + qb > q_cap) {
         // queue overflow (a tile of dense noise): score every pixel on both sides, no survivors list;
@@ -397,6 +437,9 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
     }
     __syncthreads();
     ORBX_STAMP(B, stamp_base + 1, t0);
+#ifdef ORBX_FAST_STOP
+    if (ORBX_FAST_STOP == 3) return;
+#endif
     // ---- 3. non-max suppression; survivors are listed and counted per cell ----
     // A pixel is a corner on one side at most (two arcs of 9 do not fit a ring of 16), so the corner
     // list holds no pixel twice.  It is used when it and the survivors it can add both fit beside the
@@ -462,7 +505,9 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
         if (keep && q >= qf) {
             const uint8_t* p = s_tile + ((ke >> 8 & 0x3F) + 3) * TP + 4 + (ke & 0xFF);
             const int cv = p[0];
-            const bool also_front = min(max(cv - (int)p[3 * TP], cv - (int)p[-3 * TP]), max(cv - (int)p[3], cv - (int)p[-3])) > thr;
+            const bool also_front = min(min(max(cv - (int)p[3 * TP], cv - (int)p[-3 * TP]), max(cv - (int)p[3], cv - (int)p[-3])),
+                                        min(max(cv - (int)p[2 * TP + 2], cv - (int)p[-2 * TP - 2]),
+                                            max(cv - (int)p[-2 * TP + 2], cv - (int)p[2 * TP - 2]))) > thr;
             keep = !also_front;
         }
         const uint64_t m = __ballot(keep);
@@ -489,9 +534,10 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
 }
 
 // One workgroup per tile (a run of up to kFastTileCells cells of one cell row).
-// grid = (tiles, frames), block = 256, dynamic LDS = tile + score plane + queue + kept list.
+// grid = (tiles, frames), block = 256, dynamic LDS = tile + score plane + queue + kept list + verdict plane.
 //  pass 0, threshold iniTh, all cells of the tile:
-//   1. every detection pixel takes the compass-pair rejection test; survivors go to an LDS queue;
+//   1. every detection pixel takes the compass-pair rejection test; the verdicts go to a byte plane, which
+//      a second sweep (1b) compacts into an LDS queue of survivors;
 //   2. queued pixels get the full segment-test score S; S > t stores score S-1 in a score plane
 //      in which the cells are separated by a zero column, so that
 //   3. strict 3x3 non-max suppression over the plane is cell-local exactly as when cv::FAST runs
@@ -502,7 +548,8 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
 //  is its rank among the listed survivors (the list key is cell | row | column).
 __global__ __launch_bounds__(256) void k_fast_tiles(BatchDev B, const TileDesc* __restrict__ tiles,
                                                     uint32_t* __restrict__ cand, uint32_t* __restrict__ ccount,
-                                                    int tile_bytes, int plane_bytes, int queue_bytes, int frame_major) {
+                                                    int tile_bytes, int plane_bytes, int queue_bytes, int kept_bytes,
+                                                    int verdict_bytes, int frame_major) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
     __shared__ FastShared sh;
 
@@ -510,6 +557,7 @@ __global__ __launch_bounds__(256) void k_fast_tiles(BatchDev B, const TileDesc* 
     uint8_t* s_score = s_mem + tile_bytes;
     uint16_t* s_queue = reinterpret_cast<uint16_t*>(s_score + plane_bytes);
     uint16_t* s_keptl = reinterpret_cast<uint16_t*>(s_score + plane_bytes + queue_bytes);
+    uint8_t* s_verdict = s_score + plane_bytes + queue_bytes + kept_bytes;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // grid = (tiles, frames), or (frames of a group of 8, tiles, groups) when the frames are dealt over
@@ -558,6 +606,8 @@ __global__ __launch_bounds__(256) void k_fast_tiles(BatchDev B, const TileDesc* 
         }
     }
     for (int i = tid; i < plane_bytes >> 2; i += 256) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
+    // the padding items at the end of each verdict row are never written by step 1 and must read as "no hit"
+    for (int i = tid; i < verdict_bytes >> 2; i += 256) reinterpret_cast<uint32_t*>(s_verdict)[i] = 0;
     if (tid < kFastTileCells) {
         sh.kept[tid] = 0;
         sh.th[tid] = 0;
@@ -568,16 +618,34 @@ __global__ __launch_bounds__(256) void k_fast_tiles(BatchDev B, const TileDesc* 
     }
     __syncthreads();
     ORBX_STAMP(B, 0, t0);
+#ifdef ORBX_FAST_STOP  // diagnostic build: the kernel ends after phase ORBX_FAST_STOP (cost breakdown by differences)
+#define ORBX_FAST_STOP_AT(k)                                                                               \
+    if (ORBX_FAST_STOP == (k)) {                                                                           \
+        if (tid < nc) ccount[(uint64_t)frame * B.total_cells + td.slot0 + tid] = 0;                        \
+        return;                                                                                            \
+    }
+#else
+#define ORBX_FAST_STOP_AT(k)
+#endif
+    ORBX_FAST_STOP_AT(1)
 
-    fast_pass<false>(s_tile, s_score, s_queue, s_keptl, &sh, TP, SP, wd, hd, nc, inv_wcell, B.ini_th, q_cap, k_cap, B, 1);
+    fast_pass<false>(s_tile, s_score, s_queue, s_keptl, s_verdict, &sh, TP, SP, wd, hd, nc, inv_wcell, B.ini_th, q_cap, k_cap, B, 1);
+#ifdef ORBX_FAST_STOP
+    if (ORBX_FAST_STOP == 2 || ORBX_FAST_STOP == 3) {
+        if (tid < nc) ccount[(uint64_t)frame * B.total_cells + td.slot0 + tid] = 0;
+        return;
+    }
+#endif
     if (tid < nc) {
         const bool retry = sh.kept[tid] == 0;
         sh.th[tid] = retry ? 0 : -1;
         if (retry) sh.retry = 1;
     }
     __syncthreads();
+    ORBX_FAST_STOP_AT(4)
     if (sh.retry)
-        fast_pass<true>(s_tile, s_score, s_queue, s_keptl, &sh, TP, SP, wd, hd, nc, inv_wcell, B.min_th, q_cap, k_cap, B, 4);
+        fast_pass<true>(s_tile, s_score, s_queue, s_keptl, s_verdict, &sh, TP, SP, wd, hd, nc, inv_wcell, B.min_th, q_cap, k_cap, B, 4);
+    ORBX_FAST_STOP_AT(5)
 
     // ---- ordered output ----
 #ifdef ORBX_STAMPS

@@ -88,7 +88,7 @@ struct orbx_ctx {
     std::vector<TileDesc> tiles;
     int rs_pitch[ORBX_MAX_LEVELS], rs_rows[ORBX_MAX_LEVELS];  // resize source tile in LDS
     bool rs_stream[ORBX_MAX_LEVELS];                          // level built by k_resize_rows
-    int fast_tile_bytes = 0, fast_plane_bytes = 0, fast_queue_bytes = 0;
+    int fast_tile_bytes = 0, fast_plane_bytes = 0, fast_queue_bytes = 0, fast_kept_bytes = 0, fast_verdict_bytes = 0;
     size_t fast_lds = 0;
     int pitch[ORBX_MAX_LEVELS];
     size_t plane[ORBX_MAX_LEVELS];
@@ -253,18 +253,21 @@ int set_geometry(orbx_ctx* c, int w, int h) {
     }
     std::vector<TileDesc> tiles;
     build_fast_tiles(levels, cells, &tiles);
-    int tile_b = 0, plane_b = 0, queue_b = 0, kept_b = 0;
+    int tile_b = 0, plane_b = 0, queue_b = 0, kept_b = 0, verdict_b = 0;
     for (const TileDesc& t : tiles) {
         const FastLds need = fast_lds_need(t.wd, t.hd, t.nc);
         tile_b = std::max(tile_b, need.tile);
         plane_b = std::max(plane_b, need.plane);
         queue_b = std::max(queue_b, need.queue);
         kept_b = std::max(kept_b, need.kept);
+        verdict_b = std::max(verdict_b, need.verdict);
     }
+    kept_b = (int)align_up((size_t)kept_b, 16);
+    verdict_b = (int)align_up((size_t)verdict_b, 16);
     queue_b = (int)align_up((size_t)queue_b, 16);
     tile_b = (int)align_up((size_t)tile_b, 16);
     plane_b = (int)align_up((size_t)plane_b, 16);
-    const size_t fast_lds = (size_t)tile_b + (size_t)plane_b + (size_t)queue_b + (size_t)kept_b + 16;
+    const size_t fast_lds = (size_t)tile_b + (size_t)plane_b + (size_t)queue_b + (size_t)kept_b + (size_t)verdict_b + 16;
     if (fast_lds > 160 * 1024 - 256) return ORBX_E_GEOMETRY;
     { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     rc = ensure(c, &c->d_cells, cells.size() * sizeof(CellDesc));
@@ -325,6 +328,8 @@ int set_geometry(orbx_ctx* c, int w, int h) {
     c->fast_tile_bytes = tile_b;
     c->fast_plane_bytes = plane_b;
     c->fast_queue_bytes = queue_b;
+    c->fast_kept_bytes = kept_b;
+    c->fast_verdict_bytes = verdict_b;
     c->fast_lds = fast_lds;
     c->cell_cap = cell_cap;
     c->total_cells = (int)c->cells.size();
@@ -515,7 +520,8 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
             const dim3 grid = fm ? dim3(8, (unsigned)count, (unsigned)((n + 7) / 8)) : dim3((unsigned)count, n);
             hipLaunchKernelGGL(k_fast_tiles, grid, dim3(256), c->fast_lds, st, B,
                                (const TileDesc*)c->d_tiles.p + first, (uint32_t*)c->d_cand.p, (uint32_t*)c->d_ccount.p,
-                               c->fast_tile_bytes, c->fast_plane_bytes, c->fast_queue_bytes, fm ? 1 : 0);
+                               c->fast_tile_bytes, c->fast_plane_bytes, c->fast_queue_bytes, c->fast_kept_bytes,
+                               c->fast_verdict_bytes, fm ? 1 : 0);
         }
     };
     if (overlap) {
