@@ -282,6 +282,34 @@ int orbx_search_by_projection_batch_device(orbx_ctx* ctx, int n, const orbx_kp* 
                                            const orbx_map_query* d_queries, int q_cap, const int32_t* d_nq,
                                            int32_t* d_match, int32_t* d_query_match, int32_t* d_nmatches, int sync);
 
+/* ---- descriptor consumer: ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) ----
+ * Replaces the local-map search of Tracking::SearchLocalPoints (reference src/ORBmatcher.cc:45-129,
+ * RadiusByViewingCos :131-137) for a batch of frames: every map point that Frame::isInFrustum found in
+ * view comes with its projection; its window (radius 2.5 or 4.0 by the viewing cosine, times th when
+ * th != 1, times the scale factor of the predicted level; levels predicted - 1 .. predicted) is searched
+ * for the best and the second best descriptor distance, a best distance <= 100 is accepted unless both
+ * lie on one level and best > nn_ratio * second (mfNNratio), and the match is written to the frame at
+ * once, so that later points skip features held by a point with observations (:87-89).  The result is
+ * that of the reference's sequential loop; the points are searched concurrently in rounds.
+ * d_queries[f*q_cap + i], i < d_nq[f]: map point i.  d_taken (may be null): features that hold a map
+ * point with observations before the call.  d_u_right (mvuRight) may be null.  Scale factors are the
+ * context's.  Outputs: d_match[f*kp_cap + k] = index i of the map point feature k ends with (-1: the
+ * call wrote none); d_query_match[f*q_cap + i] = the feature point i was written to (-1: none);
+ * d_nmatches[f] = the reference's return value. */
+typedef struct orbx_local_query {
+    float u, v, ur;    /* MapPoint::mTrackProjX, mTrackProjY, mTrackProjXR */
+    int32_t level;     /* mnTrackScaleLevel */
+    float view_cos;    /* mTrackViewCos */
+    int32_t flags;     /* bit 0: Observations() > 0; bit 1: skip (!mbTrackInView or isBad()) */
+    uint8_t desc[32];  /* MapPoint::GetDescriptor */
+} orbx_local_query; /* 56 bytes */
+int orbx_search_local_map_batch_device(orbx_ctx* ctx, int n, const orbx_kp* d_kps_un, int kp_cap,
+                                       const int32_t* d_cell_start, const int32_t* d_cell_idx, const uint8_t* d_desc,
+                                       const float* d_u_right, const uint8_t* d_taken, float min_x, float min_y,
+                                       float inv_w, float inv_h, float th, float nn_ratio,
+                                       const orbx_local_query* d_queries, int q_cap, const int32_t* d_nq,
+                                       int32_t* d_match, int32_t* d_query_match, int32_t* d_nmatches, int sync);
+
 /* ---- the stage after the extractor: stereo association ---------------------------------
  * Replaces Frame::ComputeStereoMatches (reference src/Frame.cc:485-659, descriptor distance
  * src/ORBmatcher.cc:1684-1700): for every left keypoint the best right keypoint in its row

@@ -1428,3 +1428,82 @@ extern "C" int orc_search_by_projection(const float* kps_xy, const int32_t* octa
     }
     return nmatches;
 }
+
+// ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (reference src/ORBmatcher.cc:45-129,
+// RadiusByViewingCos :131-137), the local-map search of Tracking::SearchLocalPoints.  A query is a map
+// point as Frame::isInFrustum left it: mTrackProjX / Y / XR, mnTrackScaleLevel, mTrackViewCos;
+// flags bit 0: Observations() > 0, bit 1: skipped (!mbTrackInView or isBad()).  match[k] = index of
+// the map point feature k holds after the call (-1: the call wrote none), query_match[i] = the
+// feature point i was written to (-1: none); returns nmatches.
+extern "C" int orc_search_local_map(const float* kps_xy, const int32_t* octave, const uint8_t* desc, const float* u_right,
+                                    const uint8_t* taken0, int n_kp, const int32_t* cell_start, const int32_t* cell_idx,
+                                    const float* scale_factors, float min_x, float min_y, float inv_w, float inv_h, float th,
+                                    float nn_ratio, const orc_local_query* q, int nq, int32_t* match, int32_t* query_match) {
+    const int TH_HIGH = 100, COLS = 64, ROWS = 48;
+    int nmatches = 0;
+    std::vector<uint8_t> blocked((size_t)std::max(n_kp, 1), 0);
+    for (int i = 0; i < n_kp; i++) {
+        blocked[i] = taken0 ? taken0[i] : 0;
+        match[i] = -1;
+    }
+    const bool bFactor = th != 1.0;  // :49
+    for (int iMP = 0; iMP < nq; iMP++) {
+        query_match[iMP] = -1;
+        if (q[iMP].flags & 2) continue;  // :54-58
+        const int nPredictedLevel = q[iMP].level;
+        float r = (double)q[iMP].view_cos > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos
+        if (bFactor) r *= th;
+        // GetFeaturesInArea(mTrackProjX, mTrackProjY, r * mvScaleFactors[level], level - 1, level), src/Frame.cc:338-396
+        const float x = q[iMP].u, y = q[iMP].v, rr = r * scale_factors[nPredictedLevel];
+        const int minLevel = nPredictedLevel - 1, maxLevel = nPredictedLevel;
+        const int nMinCellX = std::max(0, (int)std::floor((x - min_x - rr) * inv_w));
+        if (nMinCellX >= COLS) continue;
+        const int nMaxCellX = std::min(COLS - 1, (int)std::ceil((x - min_x + rr) * inv_w));
+        if (nMaxCellX < 0) continue;
+        const int nMinCellY = std::max(0, (int)std::floor((y - min_y - rr) * inv_h));
+        if (nMinCellY >= ROWS) continue;
+        const int nMaxCellY = std::min(ROWS - 1, (int)std::ceil((y - min_y + rr) * inv_h));
+        if (nMaxCellY < 0) continue;
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;  // :76-80
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                const int c = ix * ROWS + iy;
+                for (int j = cell_start[c]; j < cell_start[c + 1]; j++) {
+                    const int idx = cell_idx[j];
+                    if (bCheckLevels) {
+                        if (octave[idx] < minLevel) continue;
+                        if (maxLevel >= 0)
+                            if (octave[idx] > maxLevel) continue;
+                    }
+                    const float distx = kps_xy[2 * idx] - x;
+                    const float disty = kps_xy[2 * idx + 1] - y;
+                    if (!(std::fabs(distx) < rr && std::fabs(disty) < rr)) continue;
+                    if (blocked[idx]) continue;  // :87-89
+                    if (u_right && u_right[idx] > 0) {  // :91-96
+                        const float er = std::fabs(q[iMP].ur - u_right[idx]);
+                        if (er > r * scale_factors[nPredictedLevel]) continue;
+                    }
+                    const int dist = orc_descriptor_distance(q[iMP].desc, desc + (size_t)idx * 32);
+                    if (dist < bestDist) {  // :102-114
+                        bestDist2 = bestDist;
+                        bestDist = dist;
+                        bestLevel2 = bestLevel;
+                        bestLevel = octave[idx];
+                        bestIdx = idx;
+                    } else if (dist < bestDist2) {
+                        bestLevel2 = octave[idx];
+                        bestDist2 = dist;
+                    }
+                }
+            }
+        if (bestDist <= TH_HIGH) {  // :118-125
+            if (bestLevel == bestLevel2 && bestDist > nn_ratio * bestDist2) continue;
+            match[bestIdx] = iMP;
+            query_match[iMP] = bestIdx;
+            if (q[iMP].flags & 1) blocked[bestIdx] = 1;
+            nmatches++;
+        }
+    }
+    return nmatches;
+}

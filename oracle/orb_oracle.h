@@ -252,6 +252,19 @@ int orc_search_by_projection(const float* kps_xy, const int32_t* octave, const f
                              const float Tcw[12], const float Tlw[12], const orc_map_query* q, int nq,
                              int32_t* match, int32_t* query_match);
 
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:45-129) */
+typedef struct orc_local_query {
+    float u, v, ur;    /* MapPoint::mTrackProjX, mTrackProjY, mTrackProjXR */
+    int32_t level;     /* mnTrackScaleLevel */
+    float view_cos;    /* mTrackViewCos */
+    int32_t flags;     /* bit 0: Observations() > 0; bit 1: skip (!mbTrackInView or isBad()) */
+    uint8_t desc[32];  /* GetDescriptor() */
+} orc_local_query;
+int orc_search_local_map(const float* kps_xy, const int32_t* octave, const uint8_t* desc, const float* u_right,
+                         const uint8_t* taken0, int n_kp, const int32_t* cell_start, const int32_t* cell_idx,
+                         const float* scale_factors, float min_x, float min_y, float inv_w, float inv_h, float th,
+                         float nn_ratio, const orc_local_query* q, int nq, int32_t* match, int32_t* query_match);
+
 #ifdef __cplusplus
 }
 #endif

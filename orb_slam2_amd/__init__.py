@@ -53,7 +53,7 @@ EXPORTS = [
     "orbx_undistort_grid_batch_device",
     "orbx_voc_create", "orbx_voc_load_text", "orbx_voc_destroy", "orbx_voc_info", "orbx_voc_node", "orbx_bow_transform_batch_device", "orbx_search_window_batch_device",
     "orbx_search_by_projection_batch_device", "orbx_set_debug_flag",
-    "orbx_stereo_match_batch_device_noalloc",
+    "orbx_stereo_match_batch_device_noalloc", "orbx_search_local_map_batch_device",
 ]
 
 _lib = None
@@ -94,6 +94,8 @@ def load_library():
     L.orbx_search_window_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp, i32, vp, vp,
                                                   vp, i32]
     L.orbx_search_by_projection_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32]
+    L.orbx_search_local_map_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, vp, i32, vp,
+                                                     vp, vp, vp, i32]
     L.orbx_gray_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, i32, i32, vp, i32, C.c_size_t, i32]
     L.orbx_remap_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, vp, vp, i32, vp, i32, i32, i32,
                                           C.c_size_t, i32]
@@ -356,6 +358,18 @@ class ORBextractor:
             q_cap, C.c_void_p(d_nq), C.c_void_p(d_match), C.c_void_p(d_query_match), C.c_void_p(d_nmatches), int(sync)),
             self._ctx)
 
+    def search_local_map_batch_device(self, n, d_kps_un, kp_cap, d_cell_start, d_cell_idx, d_desc, d_u_right, d_taken, min_x,
+                                      min_y, inv_w, inv_h, th, nn_ratio, d_queries, q_cap, d_nq, d_match, d_query_match,
+                                      d_nmatches, sync=True):
+        """ORBmatcher::SearchByProjection(F, vpMapPoints, th) (src/ORBmatcher.cc:45-129) for a batch of frames: d_queries
+        holds q_cap LOCAL_QUERY_DTYPE records per frame; d_u_right / d_taken may be 0; see
+        orbx_search_local_map_batch_device."""
+        _check(self._L.orbx_search_local_map_batch_device(
+            self._ctx, n, C.c_void_p(d_kps_un), kp_cap, C.c_void_p(d_cell_start), C.c_void_p(d_cell_idx), C.c_void_p(d_desc),
+            C.c_void_p(d_u_right or None), C.c_void_p(d_taken or None), min_x, min_y, inv_w, inv_h, th, nn_ratio,
+            C.c_void_p(d_queries), q_cap, C.c_void_p(d_nq), C.c_void_p(d_match), C.c_void_p(d_query_match),
+            C.c_void_p(d_nmatches), int(sync)), self._ctx)
+
     # ---- the stage after the extractor: Frame::ComputeStereoMatches (src/Frame.cc:485-659) ----
     def stereo_match(self, right, mb, mbf, img_left=0, img_right=0):
         """Associates image `img_left` of this extractor's last host-memory extraction with image
@@ -436,6 +450,9 @@ assert WINDOW_QUERY_DTYPE.itemsize == 56
 MAP_QUERY_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("z", np.float32), ("octave", np.int32),
                             ("angle", np.float32), ("flags", np.int32), ("desc", np.uint8, (32,))])
 assert MAP_QUERY_DTYPE.itemsize == 56
+LOCAL_QUERY_DTYPE = np.dtype([("u", np.float32), ("v", np.float32), ("ur", np.float32), ("level", np.int32),
+                              ("view_cos", np.float32), ("flags", np.int32), ("desc", np.uint8, (32,))])
+assert LOCAL_QUERY_DTYPE.itemsize == 56
 PROJECTION_PARAMS_DTYPE = np.dtype([(k, np.float32) for k in ("fx", "fy", "cx", "cy", "mbf", "mb", "min_x", "min_y", "max_x",
                                                               "max_y", "inv_w", "inv_h", "th")] +
                                    [("mono", np.int32), ("check_orientation", np.int32)])

@@ -264,7 +264,7 @@ struct WindowDev {
 // the minimum of (distance, entry number).  All sixteen lanes of a group call this together; each
 // receives the winner (-1: none) and its key (distance in bits 23..31, 0xFFFFFFFF: none).
 // held(i2) tells whether feature i2 holds a map point the query must respect;
-// on_cand(i2, dist, key) runs for every candidate that passes the filters.
+// on_cand(i2, dist, key, octave) runs for every candidate that passes the filters.
 template <class Held, class OnCand>
 __device__ __forceinline__ void window_best(const WindowDev& W, int f, float x, float y, float r, float ur, int minLevel,
                                             int maxLevel, const uint4& d0, const uint4& d1, int sub, Held held,
@@ -327,7 +327,7 @@ __device__ __forceinline__ void window_best(const WindowDev& W, int f, float x, 
                                               __popc(d0.w ^ da.w) + __popc(d1.x ^ db.x) + __popc(d1.y ^ db.y) +
                                               __popc(d1.z ^ db.z) + __popc(d1.w ^ db.w);
                         const uint32_t kc = (dist << 23) | (order0 + (uint32_t)e);
-                        on_cand(i2, dist, kc);
+                        on_cand(i2, dist, kc, kp.octave);
                         if (dist < 256u && kc < key) {  // bestDist starts at 256, strict "<" (:1456)
                             key = kc;
                             mine = i2;
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void k_search_window(WindowDev W, const Window
     uint32_t kmin;
     const uint8_t* taken = W.taken ? W.taken + (size_t)f * W.kp_cap : nullptr;
     window_best(W, f, Q->u, Q->v, Q->radius, Q->ur, Q->min_level, Q->max_level, d0, d1, sub,
-                [&](int i2) { return taken && taken[i2]; }, [](int, uint32_t, uint32_t) {}, &win, &kmin);
+                [&](int i2) { return taken && taken[i2]; }, [](int, uint32_t, uint32_t, int) {}, &win, &kmin);
     if (sub == 0) {
         const size_t o = (size_t)f * W.q_cap + q;
         best_idx[o] = win;
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(kProjThreads) void k_search_projection(ProjDev D) {
                     int win;
                     uint32_t key;
                     window_best(D.W, f, u, v, radius, ur, lo, hi, d0, d1, sub, [&](int i2) { return held[i2] < q; },
-                                [&](int i2, uint32_t dist, uint32_t kc) {
+                                [&](int i2, uint32_t dist, uint32_t kc, int) {
                                     if (dist > (uint32_t)kThHigh) return;
                                     if (holds) atomicMin(&minq[i2], q);
                                     if (round == 0) {
@@ -661,6 +661,181 @@ __global__ __launch_bounds__(kProjThreads) void k_search_projection(ProjDev D) {
     for (int i = tid; i < kp_cap; i += kProjThreads) {
         const int m = __hip_atomic_load(&match[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         match[i] = (m < 0 || held[i] == -2) ? -1 : (m & 0x3FFFFFFF);
+    }
+    if (tid == 0) D.n_matches[f] = s_nm;
+}
+
+// ---- ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th): the local-map search ----
+// (reference src/ORBmatcher.cc:45-129, called from Tracking::SearchLocalPoints).  Every map point in view
+// comes with its projection (Frame::isInFrustum left it in the MapPoint); the function searches the window
+// of each, keeps the best and the second best distance, applies the ratio test when both lie on one pyramid
+// level, and writes the match into the frame at once, so that later points skip features held by a point
+// with observations.  That loop-carried dependence is kept exactly with the rounds of k_search_projection:
+// all undecided points search at the same time; a feature records the index of the point that holds it, a
+// point respects only holders below itself, and holders mark every feature they may still take (distance
+// <= TH_HIGH) with the lowest such index.  A point's outcome stands when no undecided holder below it may
+// still take its best or its second best feature: taking any other feature away changes neither of the two
+// and so neither the threshold test nor the ratio test.  The lowest undecided point always qualifies.
+// The reference's update rule (:102-114) leaves in (bestDist2, bestLevel2) the candidate with the second
+// smallest (distance, visiting order): sixteen lanes keep their two smallest keys and merge them.
+struct LocalQuery {      // a map point of the local map
+    float u, v, ur;      // mTrackProjX, mTrackProjY, mTrackProjXR
+    int32_t level;       // mnTrackScaleLevel
+    float view_cos;      // mTrackViewCos
+    int32_t flags;       // bit 0: the map point has observations (it holds what it takes); bit 1: skip
+    uint8_t desc[32];    // the map point's descriptor
+};
+static_assert(sizeof(LocalQuery) == 56, "LocalQuery layout");
+
+struct LocalDev {
+    WindowDev W;             // taken unused
+    float scale[ORBX_MAX_LEVELS];
+    float th, nn_ratio;
+    const LocalQuery* queries;  // [n][q_cap]
+    const int32_t* n_q;         // [n]
+    const uint8_t* taken0;      // [n][kp_cap] or null
+    int32_t* match;             // [n][kp_cap]
+    int32_t* query_match;       // [n][q_cap]
+    int32_t* n_matches;         // [n]
+    int32_t* minq;              // scratch [n][kp_cap]
+    int32_t* held;              // scratch [n][kp_cap]
+    int32_t* list;              // scratch [n][2][q_cap]
+    int2* pick;                 // scratch [n][q_cap]: (best, second best) feature of an undecided point, -1: none
+    int32_t use_lds;            // minq, held and list live in the workgroup's dynamic LDS (2 * kp_cap + 2 * q_cap ints)
+};
+
+// Merges the two smallest keys of another lane into (k1, k2); the values ride along.
+__device__ __forceinline__ void top2_merge(uint32_t& k1, uint32_t& k2, int& v1, int& v2, uint32_t o1, uint32_t o2, int w1, int w2) {
+    if (o1 < k1) {
+        const bool second_mine = k1 < o2;   // the old best or the other lane's second comes next
+        k2 = second_mine ? k1 : o2;
+        v2 = second_mine ? v1 : w2;
+        k1 = o1;
+        v1 = w1;
+    } else if (o1 < k2) {
+        k2 = o1;
+        v2 = w1;
+    }
+}
+
+// grid = frames, block = 1024 (64 groups of sixteen lanes).
+__global__ __launch_bounds__(kProjThreads) void k_search_local(LocalDev D) {
+    __shared__ int s_left, s_nm;
+    const int f = blockIdx.x, tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
+    const int kp_cap = D.W.kp_cap, q_cap = D.W.q_cap;
+    const int nq = min(D.n_q[f], q_cap);
+    const LocalQuery* Q = D.queries + (size_t)f * q_cap;
+    int32_t* qm = D.query_match + (size_t)f * q_cap;
+    int32_t* match = D.match + (size_t)f * kp_cap;
+    extern __shared__ int32_t s_dyn[];
+    int32_t* minq = D.use_lds ? s_dyn : D.minq + (size_t)f * kp_cap;
+    int32_t* held = D.use_lds ? s_dyn + kp_cap : D.held + (size_t)f * kp_cap;
+    int32_t* lists = D.use_lds ? s_dyn + 2 * kp_cap : D.list + (size_t)f * 2 * q_cap;
+    int2* pick = D.pick + (size_t)f * q_cap;
+    const bool factor = (double)D.th != 1.0;  // :49
+
+    for (int i = tid; i < kp_cap; i += kProjThreads) {
+        held[i] = (D.taken0 && D.taken0[(size_t)f * kp_cap + i]) ? -1 : 0x7FFFFFFF;
+        match[i] = -1;
+    }
+    for (int q = tid; q < q_cap; q += kProjThreads) qm[q] = -1;
+    if (tid == 0) s_nm = 0;
+    __syncthreads();
+
+    int n_list = nq;
+    for (int round = 0; round <= nq && n_list > 0; ++round) {  // every round decides at least the lowest undecided point
+        const int32_t* cur = lists + (size_t)(round & 1) * q_cap;
+        int32_t* next = lists + (size_t)((round + 1) & 1) * q_cap;
+        for (int i = tid; i < kp_cap; i += kProjThreads) minq[i] = 0x7FFFFFFF;
+        if (tid == 0) s_left = 0;
+        __syncthreads();
+        // every undecided point searches its window among the features no point below it holds
+        for (int e = grp; e < n_list; e += kProjThreads / 16) {
+            const int q = round == 0 ? e : cur[e];
+            const LocalQuery* m = Q + q;
+            int best = -1, second = -1, outcome = -1;
+            if (!(m->flags & 2)) {  // :54-58
+                const int level = min(max(m->level, 0), ORBX_MAX_LEVELS - 1);
+                float r = (double)m->view_cos > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos (:131-137)
+                if (factor) r = __fmul_rn(r, D.th);
+                const float radius = __fmul_rn(r, D.scale[level]);  // :69
+                const uint4 d0 = *reinterpret_cast<const uint4_unaligned*>(m->desc);
+                const uint4 d1 = *reinterpret_cast<const uint4_unaligned*>(m->desc + 16);
+                const bool holds = m->flags & 1;
+                uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+                int v1 = -1, v2 = -1;  // feature | octave << 20
+                int win;
+                uint32_t key;
+                window_best(D.W, f, m->u, m->v, radius, m->ur, m->level - 1, m->level, d0, d1, sub,
+                            [&](int i2) { return held[i2] < q; },
+                            [&](int i2, uint32_t dist, uint32_t kc, int octave) {
+                                if (holds && dist <= (uint32_t)kThHigh) atomicMin(&minq[i2], q);
+                                const int val = i2 | (octave << 20);
+                                if (kc < k1) {
+                                    k2 = k1;
+                                    v2 = v1;
+                                    k1 = kc;
+                                    v1 = val;
+                                } else if (kc < k2) {
+                                    k2 = kc;
+                                    v2 = val;
+                                }
+                            },
+                            &win, &key);
+                // the group's two smallest keys (keys are unique: the visiting order is part of them)
+#pragma unroll
+                for (int d = 8; d >= 1; d >>= 1) {
+                    const uint32_t o1 = (uint32_t)__shfl_xor((int)k1, d, 64), o2 = (uint32_t)__shfl_xor((int)k2, d, 64);
+                    const int w1 = __shfl_xor(v1, d, 64), w2 = __shfl_xor(v2, d, 64);
+                    top2_merge(k1, k2, v1, v2, o1, o2, w1, w2);
+                }
+                if (k1 != 0xFFFFFFFFu) {
+                    const int bestDist = (int)(k1 >> 23), bestLevel = v1 >> 20;
+                    const int bestDist2 = k2 == 0xFFFFFFFFu ? 256 : (int)(k2 >> 23), bestLevel2 = k2 == 0xFFFFFFFFu ? -1 : (v2 >> 20);
+                    if (bestDist <= kThHigh) {  // :118
+                        best = v1 & 0xFFFFF;
+                        second = k2 == 0xFFFFFFFFu ? -1 : (v2 & 0xFFFFF);
+                        const bool rejected = bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(D.nn_ratio, (float)bestDist2);  // :120
+                        outcome = rejected ? -1 : best;
+                    }
+                }
+            }
+            if (sub == 0) {
+                pick[q] = make_int2(best, second);
+                qm[q] = outcome;
+            }
+        }
+        __syncthreads();
+        // the outcome of a point stands when no undecided holder below it may still take its best or second best
+        for (int e = tid; e < n_list; e += kProjThreads) {
+            const int q = round == 0 ? e : cur[e];
+            const int2 p = pick[q];
+            const bool final_ = p.x < 0 || (__hip_atomic_load(&minq[p.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= q &&
+                                            (p.y < 0 || __hip_atomic_load(&minq[p.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= q));
+            if (final_) {
+                const int win = qm[q];
+                if (win >= 0 && (Q[q].flags & 1)) held[win] = q;  // the only holder this feature will ever have
+            } else {
+                qm[q] = -1;
+                next[atomicAdd(&s_left, 1)] = q;
+            }
+        }
+        __syncthreads();
+        n_list = s_left;
+        __syncthreads();  // everyone has read s_left before the next round clears it
+    }
+    // a feature ends with the point written last: the holder if there is one (nothing follows it), else the
+    // highest index; every write counts (:123-124)
+    for (int q = tid; q < nq; q += kProjThreads) {
+        const int v = qm[q];
+        if (v < 0) continue;
+        atomicMax(&match[v], (int)(((uint32_t)(Q[q].flags & 1) << 30) | (uint32_t)q));
+        atomicAdd(&s_nm, 1);
+    }
+    __syncthreads();
+    for (int i = tid; i < kp_cap; i += kProjThreads) {
+        const int m = __hip_atomic_load(&match[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        match[i] = m < 0 ? -1 : (m & 0x3FFFFFFF);
     }
     if (tid == 0) D.n_matches[f] = s_nm;
 }

@@ -136,6 +136,7 @@ struct orbx_ctx {
     int tiles_level0 = 0;  // the first tiles_level0 entries of `tiles` belong to level 0
     // stereo stage scratch (grown on demand)
     DevBuf d_st_rows, d_st_meta, d_st_wmax, d_st_sad, d_st_u, d_st_depth;
+    DevBuf d_local_pick;  // scratch of orbx_search_local_map_batch_device (it shares minq, state and list with the call above)
     DevBuf d_proj_minq, d_proj_state, d_proj_list, d_proj_cache, d_proj_ncache;  // scratch of orbx_search_by_projection_batch_device
 
     // diagnostic switches: read from the environment once, in orbx_create; orbx_set_debug_flag changes them
@@ -1020,7 +1021,7 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
     DevBuf* bufs[] = {&c->d_cells, &c->d_tiles, &c->d_pat, &c->d_pyr[0], &c->d_pyr[1], &c->d_blur[0], &c->d_blur[1],
                       &c->d_cand, &c->d_ccount, &c->d_dense_pts, &c->d_dense_node, &c->d_lvl_kps[0], &c->d_lvl_kps[1],
                       &c->d_lvl_count[0], &c->d_lvl_count[1], &c->d_out_kps,
-                      &c->d_out_desc, &c->d_out_n, &c->d_stamps, &c->d_proj_minq, &c->d_proj_state, &c->d_proj_list, &c->d_proj_cache, &c->d_proj_ncache, &c->d_st_rows, &c->d_st_meta, &c->d_st_wmax,
+                      &c->d_out_desc, &c->d_out_n, &c->d_stamps, &c->d_proj_minq, &c->d_proj_state, &c->d_proj_list, &c->d_proj_cache, &c->d_proj_ncache, &c->d_local_pick, &c->d_st_rows, &c->d_st_meta, &c->d_st_wmax,
                       &c->d_st_sad, &c->d_st_u, &c->d_st_depth};
     for (DevBuf* b : bufs) release(b);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -1467,6 +1468,47 @@ extern "C" int orbx_search_by_projection_batch_device(orbx_ctx* c, int n, const 
     const size_t lds = ((size_t)2 * kp_cap + (size_t)2 * q_cap) * 4;
     D.use_lds = lds <= 64 * 1024 ? 1 : 0;  // two workgroups per CU keep their round state in LDS
     hipLaunchKernelGGL(k_search_projection, dim3(n), dim3(kProjThreads), D.use_lds ? lds : 0, c->stream, D);
+    HIP_TRY(c, hipGetLastError());
+    if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_search_local_map_batch_device(orbx_ctx* c, int n, const orbx_kp* d_kps_un, int kp_cap,
+                                                  const int32_t* d_cell_start, const int32_t* d_cell_idx,
+                                                  const uint8_t* d_desc, const float* d_u_right, const uint8_t* d_taken,
+                                                  float min_x, float min_y, float inv_w, float inv_h, float th,
+                                                  float nn_ratio, const orbx_local_query* d_queries, int q_cap,
+                                                  const int32_t* d_nq, int32_t* d_match, int32_t* d_query_match,
+                                                  int32_t* d_nmatches, int sync) {
+    static_assert(sizeof(orbx_local_query) == sizeof(LocalQuery), "query layout");
+    if (!c || !d_kps_un || !d_cell_start || !d_cell_idx || !d_desc || !d_queries || !d_nq || !d_match || !d_query_match ||
+        !d_nmatches || n < 1 || kp_cap < 1 || q_cap < 1 || !(th > 0.0f) || !(nn_ratio > 0.0f))
+        return ORBX_E_INVALID;
+    if (q_cap >= (1 << 30) || kp_cap >= (1 << 20)) return ORBX_E_CAPACITY;
+    HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    { int rc_ = ensure(c, &c->d_proj_minq, (size_t)n * kp_cap * 4); if (rc_) return rc_; }
+    { int rc_ = ensure(c, &c->d_proj_state, (size_t)n * kp_cap * 4); if (rc_) return rc_; }
+    { int rc_ = ensure(c, &c->d_proj_list, (size_t)n * q_cap * 8); if (rc_) return rc_; }
+    { int rc_ = ensure(c, &c->d_local_pick, (size_t)n * q_cap * 8); if (rc_) return rc_; }
+    { int rc_ = join(c); if (rc_) return rc_; }
+    LocalDev D;
+    D.W = {d_kps_un, d_cell_start, d_cell_idx, d_desc, d_u_right, nullptr, min_x, min_y, inv_w, inv_h, kp_cap, q_cap};
+    for (int i = 0; i < ORBX_MAX_LEVELS; ++i) D.scale[i] = c->tab.scale[std::min(i, c->prm.nlevels - 1)];
+    D.th = th;
+    D.nn_ratio = nn_ratio;
+    D.queries = reinterpret_cast<const LocalQuery*>(d_queries);
+    D.n_q = d_nq;
+    D.taken0 = d_taken;
+    D.match = d_match;
+    D.query_match = d_query_match;
+    D.n_matches = d_nmatches;
+    D.minq = (int32_t*)c->d_proj_minq.p;
+    D.held = (int32_t*)c->d_proj_state.p;
+    D.list = (int32_t*)c->d_proj_list.p;
+    D.pick = (int2*)c->d_local_pick.p;
+    const size_t lds = ((size_t)2 * kp_cap + (size_t)2 * q_cap) * 4;
+    D.use_lds = lds <= 64 * 1024 ? 1 : 0;
+    hipLaunchKernelGGL(k_search_local, dim3(n), dim3(kProjThreads), D.use_lds ? lds : 0, c->stream, D);
     HIP_TRY(c, hipGetLastError());
     if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     return ORBX_OK;

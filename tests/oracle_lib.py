@@ -362,6 +362,37 @@ def search_by_projection(xy, octave, angle, desc, u_right, taken0, cell_start, c
     return n, match[:n_kp], qmatch[:len(q)]
 
 
+LOCAL_QUERY_DTYPE = np.dtype([("u", np.float32), ("v", np.float32), ("ur", np.float32), ("level", np.int32),
+                              ("view_cos", np.float32), ("flags", np.int32), ("desc", np.uint8, (32,))])
+assert LOCAL_QUERY_DTYPE.itemsize == 56
+
+
+def search_local_map(xy, octave, desc, u_right, taken0, cell_start, cell_idx, scale_factors, min_x, min_y, inv_w, inv_h, th,
+                     nn_ratio, queries):
+    """ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) as the reference runs it, one map
+    point after the other; returns (nmatches, map point per feature, feature per query)."""
+    L = lib()
+    L.orc_search_local_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    xy = np.ascontiguousarray(xy, np.float32)
+    octave = np.ascontiguousarray(octave, np.int32)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    cell_start = np.ascontiguousarray(cell_start, np.int32)
+    cell_idx = np.ascontiguousarray(cell_idx, np.int32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    q = np.ascontiguousarray(queries, LOCAL_QUERY_DTYPE)
+    ur_a = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    tk_a = None if taken0 is None else np.ascontiguousarray(taken0, np.uint8)
+    n_kp = len(octave)
+    match = np.full(max(n_kp, 1), -1, np.int32)
+    qmatch = np.full(max(len(q), 1), -1, np.int32)
+    n = L.orc_search_local_map(_ptr(xy), _ptr(octave), _ptr(desc), None if ur_a is None else _ptr(ur_a),
+                               None if tk_a is None else _ptr(tk_a), n_kp, _ptr(cell_start), _ptr(cell_idx), _ptr(sf),
+                               min_x, min_y, inv_w, inv_h, th, nn_ratio, _ptr(q), len(q), _ptr(match), _ptr(qmatch))
+    return n, match[:n_kp], qmatch[:len(q)]
+
+
 class Vocabulary:
     """A DBoW2 vocabulary tree in the oracle (TemplatedVocabulary, reference
     Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h).  Arrays are per node, entry 0 = root."""
