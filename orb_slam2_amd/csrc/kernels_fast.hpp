@@ -108,9 +108,9 @@ struct FastLds {
 // reads of the (discarded) pixels between wd and the next multiple of 4 inside the row.
 __host__ __device__ inline int fast_tile_pitch(int wd) { return (wd + 14 + 15) & ~15; }
 __host__ __device__ inline int fast_plane_pitch(int wd, int nc) { return (wd + nc + 1 + 3) & ~3; }
-// Queue entries for both ends together.  Half a tile's pixels is far above what textured images
-// produce (about 15 %); a tile that overflows falls back to scoring every pixel.
-__host__ __device__ inline int fast_queue_cap(int wd, int hd) { return (((wd + 3) & ~3) * hd) / 2; }
+// Queue entries for both ends together.  A quarter of a tile's pixels is far above what textured images
+// produce (about 6 %); a tile that overflows falls back to scoring every pixel.
+__host__ __device__ inline int fast_queue_cap(int wd, int hd) { return (((wd + 3) & ~3) * hd) / 4; }
 __host__ __device__ inline int fast_kept_cap(int wd, int hd) { return (((wd + 3) & ~3) * hd) / 8 + 64; }
 // Verdict plane of step 1: one byte per work item (a dword of four pixels), rows of a multiple of four items.
 __host__ __device__ inline int fast_verdict_pitch(int wd) { return (((wd + 3) >> 2) + 3) & ~3; }
@@ -124,6 +124,7 @@ __host__ __device__ inline FastLds fast_lds_need(int wd, int hd, int nc) {
     return n;
 }
 
+constexpr int kFastFixedPitch = 160;  // fits tiles up to 131 detection columns (four cells of up to 32 pixels, or three of up to 43)
 constexpr int kFastStageDepth = 3;  // 16-byte loads in flight per thread while staging a tile
 
 // Diagnostic build only (-DORBX_STAMPS): wave 0 adds the cycles between phase boundaries into
@@ -162,18 +163,22 @@ __device__ __forceinline__ void fast_score_wave(const uint8_t* s_tile, uint8_t* 
         if (q < q_hi) {
             const int e = s_queue[q], u = e & 0xFF, vq = e >> 8;
             if (u < wd) {  // not a padding pixel of the last dword of a row
-                const uint8_t* p = s_tile + (vq + 3) * TP + 4 + u;
-                const uint32_t cv2 = (uint32_t)p[0] * 0x00010001u;
+                // w = upper left corner of the pixel's 7x7 window: every ring pixel is w[(3 + dy) * TP + 3 + dx], a
+                // constant offset when the pitch is a compile-time constant
+                const uint8_t* w = s_tile + vq * TP + 1 + u;
+#define ORBX_RING(dx, dy) ((uint32_t)w[(3 + (dy)) * TP + 3 + (dx)])
+                const uint32_t cv2 = ORBX_RING(0, 0) * 0x00010001u;
                 // ring positions 2j and 2j+1 share a register
                 uint32_t P[8];
-                P[0] = (uint32_t)p[3 * TP] | ((uint32_t)p[3 * TP + 1] << 16);
-                P[1] = (uint32_t)p[2 * TP + 2] | ((uint32_t)p[1 * TP + 3] << 16);
-                P[2] = (uint32_t)p[3] | ((uint32_t)p[-1 * TP + 3] << 16);
-                P[3] = (uint32_t)p[-2 * TP + 2] | ((uint32_t)p[-3 * TP + 1] << 16);
-                P[4] = (uint32_t)p[-3 * TP] | ((uint32_t)p[-3 * TP - 1] << 16);
-                P[5] = (uint32_t)p[-2 * TP - 2] | ((uint32_t)p[-1 * TP - 3] << 16);
-                P[6] = (uint32_t)p[-3] | ((uint32_t)p[1 * TP - 3] << 16);
-                P[7] = (uint32_t)p[2 * TP - 2] | ((uint32_t)p[3 * TP - 1] << 16);
+                P[0] = ORBX_RING(0, 3) | (ORBX_RING(1, 3) << 16);
+                P[1] = ORBX_RING(2, 2) | (ORBX_RING(3, 1) << 16);
+                P[2] = ORBX_RING(3, 0) | (ORBX_RING(3, -1) << 16);
+                P[3] = ORBX_RING(2, -2) | (ORBX_RING(1, -3) << 16);
+                P[4] = ORBX_RING(0, -3) | (ORBX_RING(-1, -3) << 16);
+                P[5] = ORBX_RING(-2, -2) | (ORBX_RING(-3, -1) << 16);
+                P[6] = ORBX_RING(-3, 0) | (ORBX_RING(-3, 1) << 16);
+                P[7] = ORBX_RING(-2, 2) | (ORBX_RING(-1, 3) << 16);
+#undef ORBX_RING
                 uint32_t D[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -243,27 +248,30 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
     // instructions again as the test itself.)
     const int ndwd = (wd + 3) >> 2, n_items = hd * ndwd, vp = fast_verdict_pitch(wd);
     const uint32_t k_thr = (uint32_t)(0x8000 - 1 - thr) * 0x00010001u;
-    // (row, dword) of item tid, advanced by 256 items per iteration without divisions
+    // (row, dword) of item tid, advanced by 256 items per iteration without divisions; the item's byte offset in
+    // the tile (row v - 3, the dword left of the item's) and in the verdict plane move along by additions
     int v = (int)(((float)tid + 0.5f) * (1.0f / (float)ndwd));
     int j = tid - v * ndwd;
     const int dv = 256 / ndwd, dj = 256 - dv * ndwd;
+    int a_t = v * TP + 4 * j, a_v = v * vp + j;
+    const int da_t = dv * TP + 4 * dj, da_v = dv * vp + dj, wrap_t = TP - 4 * ndwd, wrap_v = vp - ndwd;
     for (int i0 = 0; i0 < n_items; i0 += 256) {
         uint32_t pb[2], pd[2];  // [0]: bits 15/31 = pixels 0/2, [1]: pixels 1/3
-        // items past the end (last iteration only) test a row of the tile again; their verdicts are not stored
-        {
-            const uint8_t* pc = s_tile + __umul24((uint32_t)(min(v, hd - 1) + 3), (uint32_t)TP) + 4 * j + 4;
-            const uint32_t Cd = *reinterpret_cast<const uint32_t*>(pc);
-            const uint32_t Ud = *reinterpret_cast<const uint32_t*>(pc + 3 * TP);
-            const uint32_t Dd = *reinterpret_cast<const uint32_t*>(pc - 3 * TP);
+        // items past the end (last iteration only) do nothing
+        if (v < hd) {
+            const uint8_t* pw = s_tile + a_t;  // row v - 3 of the tile, the dword left of the item's
+            const uint32_t Cd = *reinterpret_cast<const uint32_t*>(pw + 3 * TP + 4);
+            const uint32_t Ud = *reinterpret_cast<const uint32_t*>(pw + 6 * TP + 4);
+            const uint32_t Dd = *reinterpret_cast<const uint32_t*>(pw + 4);
             // pixels +3 / -3: aligned neighbour dwords shifted into place (unaligned LDS reads are slow)
-            const uint32_t Rd = __builtin_amdgcn_alignbyte(*reinterpret_cast<const uint32_t*>(pc + 4), Cd, 3);
-            const uint32_t Ld = __builtin_amdgcn_alignbyte(Cd, *reinterpret_cast<const uint32_t*>(pc - 4), 1);
+            const uint32_t Rd = __builtin_amdgcn_alignbyte(*reinterpret_cast<const uint32_t*>(pw + 3 * TP + 8), Cd, 3);
+            const uint32_t Ld = __builtin_amdgcn_alignbyte(Cd, *reinterpret_cast<const uint32_t*>(pw + 3 * TP), 1);
             // the two diagonal pairs (ring positions 2/10 and 6/14: pixels (+-2, +-2)) join the test: an arc of 9
             // holds one pixel of each of them too
-            const uint32_t P2c = *reinterpret_cast<const uint32_t*>(pc + 2 * TP), P2p = *reinterpret_cast<const uint32_t*>(pc + 2 * TP - 4),
-                           P2n = *reinterpret_cast<const uint32_t*>(pc + 2 * TP + 4);
-            const uint32_t M2c = *reinterpret_cast<const uint32_t*>(pc - 2 * TP), M2p = *reinterpret_cast<const uint32_t*>(pc - 2 * TP - 4),
-                           M2n = *reinterpret_cast<const uint32_t*>(pc - 2 * TP + 4);
+            const uint32_t P2c = *reinterpret_cast<const uint32_t*>(pw + 5 * TP + 4), P2p = *reinterpret_cast<const uint32_t*>(pw + 5 * TP),
+                           P2n = *reinterpret_cast<const uint32_t*>(pw + 5 * TP + 8);
+            const uint32_t M2c = *reinterpret_cast<const uint32_t*>(pw + TP + 4), M2p = *reinterpret_cast<const uint32_t*>(pw + TP),
+                           M2n = *reinterpret_cast<const uint32_t*>(pw + TP + 8);
             const uint32_t Dpp = __builtin_amdgcn_alignbyte(P2n, P2c, 2), Dmp = __builtin_amdgcn_alignbyte(P2c, P2p, 2);
             const uint32_t Dpm = __builtin_amdgcn_alignbyte(M2n, M2c, 2), Dmm = __builtin_amdgcn_alignbyte(M2c, M2p, 2);
             uint32_t on[2] = {0x80008000u, 0x80008000u};
@@ -300,23 +308,25 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
                     pd[h2] &= on[h2];
                 }
             }
-        }
-        // Verdict byte of the work item: bit 2p + 1 = ring darker, bit 2p = ring brighter for pixel p of the dword.
-        // One v_perm_b32 per side gathers the four sign bytes in pixel order; the shifts fold the bit pairs of the
-        // four bytes into one.  Items past the end (last iteration only) store nothing.
-        {
+            // Verdict byte of the work item: bit 2p + 1 = ring darker, bit 2p = ring brighter for pixel p of the
+            // dword.  One v_perm_b32 per side gathers the four sign bytes in pixel order; the shifts fold the bit
+            // pairs of the four bytes into one.
             const uint32_t Bm = __builtin_amdgcn_perm(pb[1], pb[0], 0x07030501u) & 0x80808080u;
             const uint32_t Dm = __builtin_amdgcn_perm(pd[1], pd[0], 0x07030501u);
             uint32_t t = (((Dm >> 1) & 0x40404040u) | Bm) >> 6;
             t |= t >> 6;
             t |= t >> 12;
-            if (v < hd) s_verdict[__umul24((uint32_t)v, (uint32_t)vp) + j] = (uint8_t)t;
+            s_verdict[a_v] = (uint8_t)t;
         }
         v += dv;
         j += dj;
+        a_t += da_t;
+        a_v += da_v;
         if (j >= ndwd) {
             j -= ndwd;
             ++v;
+            a_t += wrap_t;
+            a_v += wrap_v;
         }
     }
     __syncthreads();
@@ -546,6 +556,10 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
 //      reference :903-907), same three steps;
 //  then the survivors are written to their cell's slot in row-major order: each one's position
 //  is its rank among the listed survivors (the list key is cell | row | column).
+// TPC: the LDS row pitch of the tile as a compile-time constant (every tile of the launch then uses it, and the
+// row offsets of the ring and of the rejection test's neighbours are instruction immediates), or 0: each tile
+// uses the smallest pitch that fits it.
+template <int TPC>
 __global__ __launch_bounds__(256) void k_fast_tiles(BatchDev B, const TileDesc* __restrict__ tiles,
                                                     uint32_t* __restrict__ cand, uint32_t* __restrict__ ccount,
                                                     int tile_bytes, int plane_bytes, int queue_bytes, int kept_bytes,
@@ -569,7 +583,7 @@ __global__ __launch_bounds__(256) void k_fast_tiles(BatchDev B, const TileDesc* 
     const LevelDev& L = B.lv[td.level];
     const uint8_t* img = L.img + (uint64_t)frame * L.plane;
     const int wd = td.wd, hd = td.hd, nc = td.nc, w_cell = td.w_cell;
-    const int TP = fast_tile_pitch(wd);
+    const int TP = TPC ? TPC : fast_tile_pitch(wd);
     const int SP = fast_plane_pitch(wd, nc);
     const int rows = hd + 6, y_top = td.y_first - 3, x_left = td.x_first - 4;
     const float inv_wcell = 1.0f / (float)w_cell;
@@ -583,7 +597,7 @@ __global__ __launch_bounds__(256) void k_fast_tiles(BatchDev B, const TileDesc* 
     // x_left + 16c.  All of a thread's loads are issued before the first LDS write, so a tile
     // costs one memory round trip, not one per chunk.
     {
-        const int nch = TP >> 4, total = rows * nch;
+        const int nch = fast_tile_pitch(wd) >> 4, total = rows * nch;  // the chunks the tile needs, whatever the pitch
         const int row_end = L.pitch - 16;  // last chunk start that keeps the load inside the row
         const float inv_nch = 1.0f / (float)nch;
         for (int i0 = 0; i0 < total; i0 += 256 * kFastStageDepth) {

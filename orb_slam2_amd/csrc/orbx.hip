@@ -88,6 +88,7 @@ struct orbx_ctx {
     std::vector<TileDesc> tiles;
     int rs_pitch[ORBX_MAX_LEVELS], rs_rows[ORBX_MAX_LEVELS];  // resize source tile in LDS
     bool rs_stream[ORBX_MAX_LEVELS];                          // level built by k_resize_rows
+    bool fast_fixed_pitch = false;
     int fast_tile_bytes = 0, fast_plane_bytes = 0, fast_queue_bytes = 0, fast_kept_bytes = 0, fast_verdict_bytes = 0;
     size_t fast_lds = 0;
     int pitch[ORBX_MAX_LEVELS];
@@ -255,8 +256,13 @@ int set_geometry(orbx_ctx* c, int w, int h) {
     std::vector<TileDesc> tiles;
     build_fast_tiles(levels, cells, &tiles);
     int tile_b = 0, plane_b = 0, queue_b = 0, kept_b = 0, verdict_b = 0;
+    // Tiles up to kFastFixedPitch bytes wide (cells up to 36 pixels) all use that pitch, so that the kernel's
+    // row offsets are constants; wider ones take the kernel with per-tile pitches.
+    bool fixed_pitch = true;
+    for (const TileDesc& t : tiles) fixed_pitch = fixed_pitch && fast_tile_pitch(t.wd) <= kFastFixedPitch;
     for (const TileDesc& t : tiles) {
-        const FastLds need = fast_lds_need(t.wd, t.hd, t.nc);
+        FastLds need = fast_lds_need(t.wd, t.hd, t.nc);
+        if (fixed_pitch) need.tile = kFastFixedPitch * (t.hd + 6) + 16;
         tile_b = std::max(tile_b, need.tile);
         plane_b = std::max(plane_b, need.plane);
         queue_b = std::max(queue_b, need.queue);
@@ -329,6 +335,7 @@ int set_geometry(orbx_ctx* c, int w, int h) {
     c->fast_tile_bytes = tile_b;
     c->fast_plane_bytes = plane_b;
     c->fast_queue_bytes = queue_b;
+    c->fast_fixed_pitch = fixed_pitch;
     c->fast_kept_bytes = kept_b;
     c->fast_verdict_bytes = verdict_b;
     c->fast_lds = fast_lds;
@@ -519,10 +526,16 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
             // whole frames (neighbouring tiles share halo rows: 1.67 GB -> 0.72 GB fetched per 512 frames)
             const bool fm = n >= 8;
             const dim3 grid = fm ? dim3(8, (unsigned)count, (unsigned)((n + 7) / 8)) : dim3((unsigned)count, n);
-            hipLaunchKernelGGL(k_fast_tiles, grid, dim3(256), c->fast_lds, st, B,
-                               (const TileDesc*)c->d_tiles.p + first, (uint32_t*)c->d_cand.p, (uint32_t*)c->d_ccount.p,
-                               c->fast_tile_bytes, c->fast_plane_bytes, c->fast_queue_bytes, c->fast_kept_bytes,
-                               c->fast_verdict_bytes, fm ? 1 : 0);
+            if (c->fast_fixed_pitch)
+                hipLaunchKernelGGL(k_fast_tiles<kFastFixedPitch>, grid, dim3(256), c->fast_lds, st, B,
+                                   (const TileDesc*)c->d_tiles.p + first, (uint32_t*)c->d_cand.p, (uint32_t*)c->d_ccount.p,
+                                   c->fast_tile_bytes, c->fast_plane_bytes, c->fast_queue_bytes, c->fast_kept_bytes,
+                                   c->fast_verdict_bytes, fm ? 1 : 0);
+            else
+                hipLaunchKernelGGL(k_fast_tiles<0>, grid, dim3(256), c->fast_lds, st, B,
+                                   (const TileDesc*)c->d_tiles.p + first, (uint32_t*)c->d_cand.p, (uint32_t*)c->d_ccount.p,
+                                   c->fast_tile_bytes, c->fast_plane_bytes, c->fast_queue_bytes, c->fast_kept_bytes,
+                                   c->fast_verdict_bytes, fm ? 1 : 0);
         }
     };
     if (overlap) {
@@ -980,7 +993,8 @@ extern "C" int orbx_create(const orbx_params* params, orbx_ctx** out) {
         if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(ORBX_E_HIP);
     c->ev_made = true;
     // every context sets the same limit, so a later context cannot lower what an earlier one relies on
-    for (const void* fn : {reinterpret_cast<const void*>(k_fast_tiles), reinterpret_cast<const void*>(k_octree),
+    for (const void* fn : {reinterpret_cast<const void*>(k_fast_tiles<0>), reinterpret_cast<const void*>(k_fast_tiles<kFastFixedPitch>),
+                           reinterpret_cast<const void*>(k_octree),
                            reinterpret_cast<const void*>(k_bow_vectors)})
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds) != hipSuccess)
             return fail(ORBX_E_HIP);
