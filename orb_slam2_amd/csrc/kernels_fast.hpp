@@ -97,6 +97,11 @@ __device__ __forceinline__ int wave_incl_scan(int x) {
     return x;
 }
 
+// 1 / n for a small positive integer n as one v_rcp_f32 (1 ulp) instead of an IEEE division (11 instructions).
+// Every use is floor((i + 0.5) / n) = (int)((i + 0.5f) * fast_rcp(n)) with i < 2^13 and n < 2^13: (i + 0.5) / n
+// stays at least 0.5 / n away from an integer, thousands of times the rounding error, so the floor is exact.
+__device__ __forceinline__ float fast_rcp(int n) { return __builtin_amdgcn_rcpf((float)n); }
+
 constexpr int kFastMaxCell = 66;  // largest sub-image side: wCell <= 59, + 6, + 1
 
 // LDS carve-up of k_fast_tiles for one tile geometry (bytes).
@@ -141,17 +146,19 @@ constexpr int kFastStageDepth = 3;  // 16-byte loads in flight per thread while 
 #endif
 
 struct FastShared {  // small per-workgroup state in static LDS
-    int q_fb;  // survivors queued so far: front end in the low 16 bits, back end in the high 16
+    int q_n;  // survivors queued so far (entries: a pixel that passes the rejection test on both sides has two)
     int n_kept, retry;
     int n_corner;  // pixels scored as corners in step 2 of the current pass
     int kept[kFastTileCells];
     int th[kFastTileCells];
 };
 
-// Full segment-test half score of the 64 queued pixels [q0, q0 + 64) below q_hi, by one wave: ring
-// darker than the centre (BRIGHT = true, a "bright" corner) or ring brighter (evaluated as
-// ring - centre).
-template <bool BRIGHT, bool RETRY>
+// Queue entry of a survivor of the rejection test: row << 9 | column << 1 | side, side 1 = ring darker than the
+// centre (a "bright" corner), 0 = ring brighter.
+// Full segment-test half score of the 64 queue entries [q0, q0 + 64) below q_hi, by one wave.  The side is a lane's
+// own: d_k = (ring_k - centre) * s with s = -1 (ring darker) or +1, one packed multiply-add per pair of ring
+// pixels, so that a wave scores entries of both sides without diverging.
+template <bool RETRY>
 __device__ __forceinline__ void fast_score_wave(const uint8_t* s_tile, uint8_t* s_score, const uint16_t* s_queue,
                                                 FastShared* sh, int q0, int q_hi, int TP, int SP, int wd, int nc,
                                                 float inv_wcell, int thr, uint16_t* s_corner_top, int corner_room) {
@@ -161,13 +168,16 @@ __device__ __forceinline__ void fast_score_wave(const uint8_t* s_tile, uint8_t* 
         bool hit = false;
         int ke = 0;
         if (q < q_hi) {
-            const int e = s_queue[q], u = e & 0xFF, vq = e >> 8;
+            const int e = s_queue[q], u = (e >> 1) & 0xFF, vq = e >> 9;
             if (u < wd) {  // not a padding pixel of the last dword of a row
                 // w = upper left corner of the pixel's 7x7 window: every ring pixel is w[(3 + dy) * TP + 3 + dx], a
                 // constant offset when the pitch is a compile-time constant
                 const uint8_t* w = s_tile + vq * TP + 1 + u;
 #define ORBX_RING(dx, dy) ((uint32_t)w[(3 + (dy)) * TP + 3 + (dx)])
-                const uint32_t cv2 = ORBX_RING(0, 0) * 0x00010001u;
+                const fast_i16x2 sgn = __builtin_bit_cast(fast_i16x2, (e & 1) ? 0xFFFFFFFFu : 0x00010001u);
+                // -centre * s in both lanes
+                const fast_i16x2 cv2 = __builtin_bit_cast(fast_i16x2, ORBX_RING(0, 0) * 0x00010001u);
+                const fast_i16x2 cs = (e & 1) ? cv2 : -cv2;
                 // ring positions 2j and 2j+1 share a register
                 uint32_t P[8];
                 P[0] = ORBX_RING(0, 3) | (ORBX_RING(1, 3) << 16);
@@ -181,17 +191,14 @@ __device__ __forceinline__ void fast_score_wave(const uint8_t* s_tile, uint8_t* 
 #undef ORBX_RING
                 uint32_t D[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const fast_i16x2 a = __builtin_bit_cast(fast_i16x2, cv2), b = __builtin_bit_cast(fast_i16x2, P[j]);
-                    D[j] = __builtin_bit_cast(uint32_t, BRIGHT ? a - b : b - a);
-                }
+                for (int j = 0; j < 8; ++j) D[j] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(fast_i16x2, P[j]) * sgn + cs);
                 const int S = arc_max_pk(D);
                 if (S > thr) {
                     const int c = min((int)(((float)u + 0.5f) * inv_wcell), nc - 1);
                     if (!RETRY || sh->th[c] >= 0) {
                         s_score[(vq + 1) * SP + 1 + u + c] = (uint8_t)(S - 1);
                         hit = true;
-                        ke = (c << 14) | e;
+                        ke = (c << 14) | (e >> 1);
                     }
                 }
             }
@@ -230,7 +237,7 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
     t0 = __builtin_amdgcn_s_memtime();
 #endif
     if (tid == 0) {
-        sh->q_fb = 0;
+        sh->q_n = 0;
         sh->n_corner = 0;
     }
     const int kept_before = sh->n_kept;  // survivors of the first pass (read before anyone adds to it: step 3 is two barriers away)
@@ -250,7 +257,7 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
     const uint32_t k_thr = (uint32_t)(0x8000 - 1 - thr) * 0x00010001u;
     // (row, dword) of item tid, advanced by 256 items per iteration without divisions; the item's byte offset in
     // the tile (row v - 3, the dword left of the item's) and in the verdict plane move along by additions
-    int v = (int)(((float)tid + 0.5f) * (1.0f / (float)ndwd));
+    int v = (int)(((float)tid + 0.5f) * fast_rcp(ndwd));
     int j = tid - v * ndwd;
     const int dv = 256 / ndwd, dj = 256 - dv * ndwd;
     int a_t = v * TP + 4 * j, a_v = v * vp + j;
@@ -330,16 +337,14 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
         }
     }
     __syncthreads();
-    // ---- 1b. the verdict plane becomes the two-ended queue ----
-    // A thread takes the verdicts of four neighbouring work items (16 pixels of one row) as one dword, the
-    // wave's prefix sums of the two counts (ring darker | ring brighter << 16, DPP scan) and ONE LDS add per
-    // wave give every lane its first slot at each end, and the lane then writes its hits one per iteration.
-    // Pixels whose ring is darker go to the front of the queue, brighter ones to its back, so that
-    // step 2 runs each half of the score on a dense range.  A wave whose reservation does not fit skips
-    // its writes; the overflow is detected after the pass.
+    // ---- 1b. the verdict plane becomes the queue ----
+    // A thread takes the verdicts of four neighbouring work items (16 pixels of one row, two sides) as one
+    // dword; the wave's prefix sum of the hit counts (DPP scan) and ONE LDS add per wave give every lane its
+    // first slot, and the lane then writes its hits one per iteration.  A wave whose reservation does not fit
+    // skips its writes; the overflow is detected after the pass.
     {
         const int vp4 = vp >> 2, n_groups = hd * vp4;
-        const float inv_vp4 = 1.0f / (float)vp4;
+        const float inv_vp4 = fast_rcp(vp4);
         const uint32_t* s_verdict32 = reinterpret_cast<const uint32_t*>(s_verdict);
         for (int g0 = 0; g0 < n_groups; g0 += 256) {
             const int g = g0 + tid;
@@ -348,10 +353,9 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
             if (g < n_groups) {
                 w = s_verdict32[g];
                 const int vg = (int)(((float)g + 0.5f) * inv_vp4);
-                ebase = (vg << 8) + 16 * (g - vg * vp4);
+                ebase = (vg << 9) + 32 * (g - vg * vp4);  // bit k of w: pixel k >> 1 of the 16, side k & 1
             }
-            uint32_t wf = w & 0xAAAAAAAAu, wb = w & 0x55555555u;  // front: ring darker; back: ring brighter
-            const int cnt = __popc(wf) | (__popc(wb) << 16);
+            const int cnt = __popc(w);
             const int incl = wave_incl_scan(cnt);
             const int tot = __builtin_amdgcn_readlane(incl, 63);
             if (tot == 0) continue;  // wave-uniform
@@ -360,28 +364,17 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
                 uint32_t got;
                 asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
                              : "=v"(got)
-                             : "v"((uint32_t)(uintptr_t)&sh->q_fb), "v"((uint32_t)tot)
+                             : "v"((uint32_t)(uintptr_t)&sh->q_n), "v"((uint32_t)tot)
                              : "memory");
                 base = (int)got;
             }
             base = __builtin_amdgcn_readfirstlane(base);
-            const int excl = incl - cnt;
-            if ((base & 0xFFFF) + (tot & 0xFFFF) > q_cap) wf = 0;
-            if ((int)((uint32_t)base >> 16) + (int)((uint32_t)tot >> 16) > q_cap) wb = 0;
-            uint16_t* qf_p = s_queue + (base & 0xFFFF) + (excl & 0xFFFF);                                   // upwards
-            uint16_t* qb_p = s_queue + (q_cap - 1) - ((int)((uint32_t)base >> 16) + (int)((uint32_t)excl >> 16));  // downwards
-            while (__builtin_amdgcn_ballot_w64(wf != 0)) {
-                if (wf) {
-                    const int k = __builtin_ctz(wf);
-                    *qf_p++ = (uint16_t)(ebase + (k >> 1));
-                    wf &= wf - 1;
-                }
-            }
-            while (__builtin_amdgcn_ballot_w64(wb != 0)) {
-                if (wb) {
-                    const int k = __builtin_ctz(wb);
-                    *qb_p-- = (uint16_t)(ebase + (k >> 1));
-                    wb &= wb - 1;
+            if (base + tot > q_cap) continue;  // wave-uniform
+            uint16_t* q_p = s_queue + base + (incl - cnt);
+            while (__builtin_amdgcn_ballot_w64(w != 0)) {
+                if (w) {
+                    *q_p++ = (uint16_t)(ebase + __builtin_ctz(w));
+                    w &= w - 1;
                 }
             }
         }
@@ -391,12 +384,12 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
 #ifdef ORBX_FAST_STOP
     if (ORBX_FAST_STOP == 2) return;
 #endif
-    const int qf = sh->q_fb & 0xFFFF, qb = (int)((uint32_t)sh->q_fb >> 16);
-    if (qf + qb > q_cap) {
+    const int qn = sh->q_n;
+    if (qn > q_cap) {
         // queue overflow (a tile of dense noise): score every pixel on both sides, no survivors list;
         // the output stage then finds the maxima by scanning the score plane
         for (int i = tid; i < wd * hd; i += 256) {
-            const int vq = (int)(((float)i + 0.5f) * (1.0f / (float)wd)), u = i - vq * wd;
+            const int vq = (int)(((float)i + 0.5f) * fast_rcp(wd)), u = i - vq * wd;
             const int c = min((int)(((float)u + 0.5f) * inv_wcell), nc - 1);
             if (RETRY && sh->th[c] < 0) continue;
             const uint8_t* p = s_tile + (vq + 3) * TP + 4 + u;
@@ -415,7 +408,7 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
         __syncthreads();
         // count the maxima per cell (the retry decision needs the counts)
         for (int i = tid; i < wd * hd; i += 256) {
-            const int vq = (int)(((float)i + 0.5f) * (1.0f / (float)wd)), u = i - vq * wd;
+            const int vq = (int)(((float)i + 0.5f) * fast_rcp(wd)), u = i - vq * wd;
             const int c = min((int)(((float)u + 0.5f) * inv_wcell), nc - 1);
             if (RETRY && sh->th[c] < 0) continue;
             const uint8_t* sp = s_score + (vq + 1) * SP + 1 + u + c;
@@ -431,20 +424,10 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
         return;
     }
     // ---- 2. full score of the queued pixels ----
-    // The two ends are cut into runs of 64 entries and the runs dealt to the four waves, so that a wave
-    // never idles through a pass over the other end: polarity is uniform per wave, not per workgroup.
+    // The queue is cut into runs of 64 entries and the runs dealt to the four waves.
     const int corner_room = max(0, min(k_cap, k_cap - kept_before));
-    {
-        const int runs_f = (qf + 63) >> 6, runs = runs_f + ((qb + 63) >> 6);
-        for (int t = tid >> 6; t < runs; t += 4) {
-            if (t < runs_f)
-                fast_score_wave<true, RETRY>(s_tile, s_score, s_queue, sh, 64 * t, qf, TP, SP, wd, nc, inv_wcell, thr,
-                                             s_keptl + k_cap - 1, corner_room);
-            else
-                fast_score_wave<false, RETRY>(s_tile, s_score, s_queue, sh, q_cap - qb + 64 * (t - runs_f), q_cap, TP, SP, wd,
-                                              nc, inv_wcell, thr, s_keptl + k_cap - 1, corner_room);
-        }
-    }
+    for (int q0 = 64 * (tid >> 6); q0 < qn; q0 += 256)
+        fast_score_wave<RETRY>(s_tile, s_score, s_queue, sh, q0, qn, TP, SP, wd, nc, inv_wcell, thr, s_keptl + k_cap - 1, corner_room);
     __syncthreads();
     ORBX_STAMP(B, stamp_base + 1, t0);
 #ifdef ORBX_FAST_STOP
@@ -492,13 +475,13 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
         ORBX_STAMP(B, stamp_base + 2, t0);
         return;
     }
-    const int n_all = qf + qb;
-    for (int q0 = 0; q0 < n_all; q0 += 256) {
+    for (int q0 = 0; q0 < qn; q0 += 256) {
         const int q = q0 + tid;
-        bool keep = false;
+        bool keep = false, darker = false;
         int ke = 0, c = 0;
-        if (q < n_all) {
-            const int e = s_queue[q < qf ? q : q_cap - qb + (q - qf)], u = e & 0xFF, vq = e >> 8;
+        if (q < qn) {
+            const int e = s_queue[q], u = (e >> 1) & 0xFF, vq = e >> 9;
+            darker = e & 1;
             if (u < wd) {
                 c = min((int)(((float)u + 0.5f) * inv_wcell), nc - 1);
                 const uint8_t* sp = s_score + (vq + 1) * SP + 1 + u + c;
@@ -507,12 +490,12 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
                     const int m = max(max(max((int)sp[-1], (int)sp[1]), max((int)sp[-SP - 1], (int)sp[-SP])),
                                       max(max((int)sp[-SP + 1], (int)sp[SP - 1]), max((int)sp[SP], (int)sp[SP + 1])));
                     keep = sc > m;
-                    ke = (c << 14) | e;
+                    ke = (c << 14) | (e >> 1);
                 }
             }
         }
-        // a pixel queued on both sides is listed once: the back copy is dropped when the front one exists
-        if (keep && q >= qf) {
+        // a pixel queued on both sides is listed once: the "ring brighter" entry is dropped when the other exists
+        if (keep && !darker) {
             const uint8_t* p = s_tile + ((ke >> 8 & 0x3F) + 3) * TP + 4 + (ke & 0xFF);
             const int cv = p[0];
             const bool also_front = min(min(max(cv - (int)p[3 * TP], cv - (int)p[-3 * TP]), max(cv - (int)p[3], cv - (int)p[-3])),
@@ -586,7 +569,7 @@ __global__ __launch_bounds__(256) void k_fast_tiles(BatchDev B, const TileDesc* 
     const int TP = TPC ? TPC : fast_tile_pitch(wd);
     const int SP = fast_plane_pitch(wd, nc);
     const int rows = hd + 6, y_top = td.y_first - 3, x_left = td.x_first - 4;
-    const float inv_wcell = 1.0f / (float)w_cell;
+    const float inv_wcell = fast_rcp(w_cell);
     const int q_cap = fast_queue_cap(wd, hd), k_cap = fast_kept_cap(wd, hd);
     unsigned long long t0 = 0;
 #ifdef ORBX_STAMPS
@@ -599,7 +582,7 @@ __global__ __launch_bounds__(256) void k_fast_tiles(BatchDev B, const TileDesc* 
     {
         const int nch = fast_tile_pitch(wd) >> 4, total = rows * nch;  // the chunks the tile needs, whatever the pitch
         const int row_end = L.pitch - 16;  // last chunk start that keeps the load inside the row
-        const float inv_nch = 1.0f / (float)nch;
+        const float inv_nch = fast_rcp(nch);
         for (int i0 = 0; i0 < total; i0 += 256 * kFastStageDepth) {
             uint4 reg[kFastStageDepth];
             int dst[kFastStageDepth];
@@ -686,7 +669,7 @@ __global__ __launch_bounds__(256) void k_fast_tiles(BatchDev B, const TileDesc* 
         for (int c = wave; c < nc; c += 4) {
             const int cwd = c < nc - 1 ? w_cell : wd - (nc - 1) * w_cell;
             const int npx = cwd * hd;
-            const float inv_cwd = 1.0f / (float)cwd;
+            const float inv_cwd = fast_rcp(cwd);
             uint32_t* out = cand + (slot0 + c) * B.cell_cap;
             int base = 0;
             for (int i0 = 0; i0 < npx; i0 += 64) {

@@ -2,13 +2,15 @@
 """Sum rocprofv3 counter rows per (kernel, counter); print per-dispatch averages."""
 import csv
 import sys
+
+from kname import is_orbx, kernel_name  # noqa: F401
 from collections import defaultdict
 
 acc = defaultdict(float)
 calls = defaultdict(set)
 with open(sys.argv[1]) as f:
     for row in csv.DictReader(f):
-        name = row["Kernel_Name"].split("(")[0]
+        name = kernel_name(row["Kernel_Name"])
         if not name.startswith("orbx::"):
             continue
         acc[(name, row["Counter_Name"])] += float(row["Counter_Value"])

@@ -3,11 +3,13 @@
 import csv
 import sys
 
+from kname import is_orbx, kernel_name  # noqa: F401
+
 rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
-        if r["Kernel_Name"].startswith("orbx::"):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0],
+        if is_orbx(r["Kernel_Name"]):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), kernel_name(r["Kernel_Name"]),
                          r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Grid_Size_Y", ""), r.get("Grid_Size_Z", "")))
 rows.sort()
 # last step = last 26 dispatches (7 resize + 1 fast + 1 octree + 8 blur + 1 describe)

@@ -14,6 +14,8 @@ import csv
 import json
 import os
 import sys
+
+from kname import is_orbx, kernel_name  # noqa: F401
 from collections import defaultdict
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,7 +26,7 @@ def per_launch(path):
     acc, ids = defaultdict(float), defaultdict(set)
     with open(path) as f:
         for row in csv.DictReader(f):
-            name = row["Kernel_Name"].split("(")[0]
+            name = kernel_name(row["Kernel_Name"])
             if not name.startswith("orbx::"):
                 continue
             acc[name] += float(row["Counter_Value"])
