@@ -226,11 +226,13 @@ __device__ __forceinline__ void fast_score_wave(const uint8_t* s_tile, uint8_t* 
 }
 
 // Steps 1-3 of one pass over a tile (see k_fast_tiles).  RETRY = false: threshold iniTh, every
-// cell; RETRY = true: threshold minTh, only the cells whose th entry is >= 0.
+// cell; RETRY = true: threshold minTh, only the cells whose th entry is >= 0.  The rejection test visits the
+// dword columns [j_lo, j_lo + ndw) of every row (the whole tile, or the columns that hold the cells to retry).
 template <bool RETRY>
 __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_score, uint16_t* s_queue, uint16_t* s_keptl,
                                           uint8_t* s_verdict, FastShared* sh, int TP, int SP, int wd, int hd, int nc,
-                                          float inv_wcell, int thr, int q_cap, int k_cap, const BatchDev& B, int stamp_base) {
+                                          float inv_wcell, int thr, int q_cap, int k_cap, const BatchDev& B, int stamp_base,
+                                          int j_lo, int ndw) {
     const int tid = threadIdx.x, lane = tid & 63;
     unsigned long long t0 = 0;
 #ifdef ORBX_STAMPS
@@ -241,6 +243,8 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
         sh->n_corner = 0;
     }
     const int kept_before = sh->n_kept;  // survivors of the first pass (read before anyone adds to it: step 3 is two barriers away)
+    if (RETRY)  // the verdicts of the first pass outside the columns this pass visits must not be queued again
+        for (int i = tid; i < (fast_verdict_pitch(wd) * hd) >> 2; i += 256) reinterpret_cast<uint32_t*>(s_verdict)[i] = 0;
     __syncthreads();
     // ---- 1. rejection test, four pixels per work item, two pixels per instruction ----
     // Any arc of 9 holds one pixel of each opposite pair, so a corner needs the two compass pairs
@@ -253,15 +257,15 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
     // The eight verdicts of a work item (four pixels, two polarities) go to a byte plane; step 1b turns the
     // plane into the queue.  (Appending to the queue here, with one ballot per verdict, cost as many vector
     // instructions again as the test itself.)
-    const int ndwd = (wd + 3) >> 2, n_items = hd * ndwd, vp = fast_verdict_pitch(wd);
+    const int n_items = hd * ndw, vp = fast_verdict_pitch(wd);
     const uint32_t k_thr = (uint32_t)(0x8000 - 1 - thr) * 0x00010001u;
     // (row, dword) of item tid, advanced by 256 items per iteration without divisions; the item's byte offset in
     // the tile (row v - 3, the dword left of the item's) and in the verdict plane move along by additions
-    int v = (int)(((float)tid + 0.5f) * fast_rcp(ndwd));
-    int j = tid - v * ndwd;
-    const int dv = 256 / ndwd, dj = 256 - dv * ndwd;
-    int a_t = v * TP + 4 * j, a_v = v * vp + j;
-    const int da_t = dv * TP + 4 * dj, da_v = dv * vp + dj, wrap_t = TP - 4 * ndwd, wrap_v = vp - ndwd;
+    int v = (int)(((float)tid + 0.5f) * fast_rcp(ndw));
+    int j = tid - v * ndw;  // relative to j_lo
+    const int dv = 256 / ndw, dj = 256 - dv * ndw;
+    int a_t = v * TP + 4 * (j + j_lo), a_v = v * vp + j + j_lo;
+    const int da_t = dv * TP + 4 * dj, da_v = dv * vp + dj, wrap_t = TP - 4 * ndw, wrap_v = vp - ndw;
     for (int i0 = 0; i0 < n_items; i0 += 256) {
         uint32_t pb[2], pd[2];  // [0]: bits 15/31 = pixels 0/2, [1]: pixels 1/3
         // items past the end (last iteration only) do nothing
@@ -285,7 +289,7 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
             if (RETRY) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    const int u = min(4 * j + b, wd - 1);
+                    const int u = min(4 * (j + j_lo) + b, wd - 1);
                     if (sh->th[min((int)(((float)u + 0.5f) * inv_wcell), nc - 1)] < 0) on[b & 1] &= ~(0x8000u << (8 * (b & 2)));
                 }
             }
@@ -329,8 +333,8 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
         j += dj;
         a_t += da_t;
         a_v += da_v;
-        if (j >= ndwd) {
-            j -= ndwd;
+        if (j >= ndw) {
+            j -= ndw;
             ++v;
             a_t += wrap_t;
             a_v += wrap_v;
@@ -626,7 +630,8 @@ __global__ __launch_bounds__(256) void k_fast_tiles(BatchDev B, const TileDesc* 
 #endif
     ORBX_FAST_STOP_AT(1)
 
-    fast_pass<false>(s_tile, s_score, s_queue, s_keptl, s_verdict, &sh, TP, SP, wd, hd, nc, inv_wcell, B.ini_th, q_cap, k_cap, B, 1);
+    fast_pass<false>(s_tile, s_score, s_queue, s_keptl, s_verdict, &sh, TP, SP, wd, hd, nc, inv_wcell, B.ini_th, q_cap, k_cap, B, 1, 0,
+                     (wd + 3) >> 2);
 #ifdef ORBX_FAST_STOP
     if (ORBX_FAST_STOP == 2 || ORBX_FAST_STOP == 3) {
         if (tid < nc) ccount[(uint64_t)frame * B.total_cells + td.slot0 + tid] = 0;
@@ -640,8 +645,17 @@ __global__ __launch_bounds__(256) void k_fast_tiles(BatchDev B, const TileDesc* 
     }
     __syncthreads();
     ORBX_FAST_STOP_AT(4)
-    if (sh.retry)
-        fast_pass<true>(s_tile, s_score, s_queue, s_keptl, s_verdict, &sh, TP, SP, wd, hd, nc, inv_wcell, B.min_th, q_cap, k_cap, B, 4);
+    if (sh.retry) {
+        // the dword columns from the first to the last cell to retry
+        int c_first = nc, c_last = 0;
+        for (int c = nc - 1; c >= 0; --c)
+            if (sh.th[c] >= 0) c_first = c;
+        for (int c = 0; c < nc; ++c)
+            if (sh.th[c] >= 0) c_last = c;
+        const int j_lo = (c_first * w_cell) >> 2, j_hi = (min((c_last + 1) * w_cell, wd) + 3) >> 2;
+        fast_pass<true>(s_tile, s_score, s_queue, s_keptl, s_verdict, &sh, TP, SP, wd, hd, nc, inv_wcell, B.min_th, q_cap, k_cap, B, 4,
+                        j_lo, j_hi - j_lo);
+    }
     ORBX_FAST_STOP_AT(5)
 
     // ---- ordered output ----
