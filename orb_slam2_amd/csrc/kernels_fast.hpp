@@ -85,6 +85,14 @@ __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(fast_u16x2, a), __builtin_bit_cast(fast_u16x2, b)));
 }
 
+// (a & mask) | (b & ~mask) as one v_bfi_b32.  Written as an instruction because the compiler, knowing that only
+// some result bits are read later, splits the expression into more instructions than it saves.
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(a), "v"(b));
+    return r;
+}
+
 // Inclusive prefix sum over the 64 lanes of a wave with DPP adds (row shifts 1, 2, 4, 8 inside the rows of
 // 16 lanes, then the row broadcasts 15 and 31); lanes a shift does not reach add 0.
 __device__ __forceinline__ int wave_incl_scan(int x) {
@@ -258,19 +266,20 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
     // plane into the queue.  (Appending to the queue here, with one ballot per verdict, cost as many vector
     // instructions again as the test itself.)
     const int n_items = hd * ndw, vp = fast_verdict_pitch(wd);
-    const uint32_t k_thr = (uint32_t)(0x8000 - 1 - thr) * 0x00010001u;
-    // (row, dword) of item tid, advanced by 256 items per iteration without divisions; the item's byte offset in
+    // the bias that moves "beyond the threshold" into a lane's bit 15 (ring darker) or bit 14 (ring brighter)
+    const uint32_t k_thr = (uint32_t)(0x8000 - 1 - thr) * 0x00010001u, k_thr2 = (uint32_t)(0x4000 - 1 - thr) * 0x00010001u;
+    // (row, dword) of item tid, advanced by 256 items per iteration without divisions; the item's place in
     // the tile (row v - 3, the dword left of the item's) and in the verdict plane move along by additions
     int v = (int)(((float)tid + 0.5f) * fast_rcp(ndw));
     int j = tid - v * ndw;  // relative to j_lo
     const int dv = 256 / ndw, dj = 256 - dv * ndw;
-    int a_t = v * TP + 4 * (j + j_lo), a_v = v * vp + j + j_lo;
+    const uint8_t* pw = s_tile + v * TP + 4 * (j + j_lo);
+    uint8_t* pv = s_verdict + v * vp + j + j_lo;
     const int da_t = dv * TP + 4 * dj, da_v = dv * vp + dj, wrap_t = TP - 4 * ndw, wrap_v = vp - ndw;
     for (int i0 = 0; i0 < n_items; i0 += 256) {
         uint32_t pb[2], pd[2];  // [0]: bits 15/31 = pixels 0/2, [1]: pixels 1/3
         // items past the end (last iteration only) do nothing
         if (v < hd) {
-            const uint8_t* pw = s_tile + a_t;  // row v - 3 of the tile, the dword left of the item's
             const uint32_t Cd = *reinterpret_cast<const uint32_t*>(pw + 3 * TP + 4);
             const uint32_t Ud = *reinterpret_cast<const uint32_t*>(pw + 6 * TP + 4);
             const uint32_t Dd = *reinterpret_cast<const uint32_t*>(pw + 4);
@@ -285,12 +294,12 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
                            M2n = *reinterpret_cast<const uint32_t*>(pw + TP + 8);
             const uint32_t Dpp = __builtin_amdgcn_alignbyte(P2n, P2c, 2), Dmp = __builtin_amdgcn_alignbyte(P2c, P2p, 2);
             const uint32_t Dpm = __builtin_amdgcn_alignbyte(M2n, M2c, 2), Dmm = __builtin_amdgcn_alignbyte(M2c, M2p, 2);
-            uint32_t on[2] = {0x80008000u, 0x80008000u};
+            uint32_t on[2] = {0xC000C000u, 0xC000C000u};
             if (RETRY) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int u = min(4 * (j + j_lo) + b, wd - 1);
-                    if (sh->th[min((int)(((float)u + 0.5f) * inv_wcell), nc - 1)] < 0) on[b & 1] &= ~(0x8000u << (8 * (b & 2)));
+                    if (sh->th[min((int)(((float)u + 0.5f) * inv_wcell), nc - 1)] < 0) on[b & 1] &= ~(0xC000u << (8 * (b & 2)));
                 }
             }
 #pragma unroll
@@ -312,32 +321,32 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
                     hi = pk_max_u16(hi, pk_max_u16(pk_min_u16(pp, mm), pk_min_u16(pm, mp)));
                     lo = pk_min_u16(lo, pk_min_u16(pk_max_u16(pp, mm), pk_max_u16(pm, mp)));
                 }
-                pb[h2] = (c + k_thr) - hi;  // only bits 15 and 31 are read
-                pd[h2] = (lo + k_thr) - c;
+                pb[h2] = (c + k_thr) - hi;   // only bits 15 and 31 are read
+                pd[h2] = (lo + k_thr2) - c;  // only bits 14 and 30 are read
                 if (RETRY) {
                     pb[h2] &= on[h2];
                     pd[h2] &= on[h2];
                 }
             }
             // Verdict byte of the work item: bit 2p + 1 = ring darker, bit 2p = ring brighter for pixel p of the
-            // dword.  One v_perm_b32 per side gathers the four sign bytes in pixel order; the shifts fold the bit
-            // pairs of the four bytes into one.
-            const uint32_t Bm = __builtin_amdgcn_perm(pb[1], pb[0], 0x07030501u) & 0x80808080u;
-            const uint32_t Dm = __builtin_amdgcn_perm(pd[1], pd[0], 0x07030501u);
-            uint32_t t = (((Dm >> 1) & 0x40404040u) | Bm) >> 6;
-            t |= t >> 6;
-            t |= t >> 12;
-            s_verdict[a_v] = (uint8_t)t;
+            // dword.  One v_perm_b32 per side gathers the four flag bytes, pixel 3 first; three bit-field inserts
+            // fold the four bit pairs into the low byte (the other bits of the operands are never read).
+            const uint32_t Bm = __builtin_amdgcn_perm(pb[1], pb[0], 0x01050307u);
+            const uint32_t Dm = __builtin_amdgcn_perm(pd[1], pd[0], 0x01050307u);
+            uint32_t t = bfi(0x80808080u, Bm, Dm);     // bits 7, 6 of every byte
+            t = bfi(0xC0C0C0C0u, t, t >> 10);          // bytes 0 and 2: pairs at bits 7..4
+            t = bfi(0x000000F0u, t, t >> 20);          // byte 0: all four pairs
+            *pv = (uint8_t)t;
         }
         v += dv;
         j += dj;
-        a_t += da_t;
-        a_v += da_v;
+        pw += da_t;
+        pv += da_v;
         if (j >= ndw) {
             j -= ndw;
             ++v;
-            a_t += wrap_t;
-            a_v += wrap_v;
+            pw += wrap_t;
+            pv += wrap_v;
         }
     }
     __syncthreads();
