@@ -85,6 +85,13 @@ __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(fast_u16x2, a), __builtin_bit_cast(fast_u16x2, b)));
 }
 
+__device__ __forceinline__ uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(fast_u16x2, a), __builtin_bit_cast(fast_u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_add_sat_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(fast_u16x2, a), __builtin_bit_cast(fast_u16x2, b)));
+}
+
 // (a & mask) | (b & ~mask) as one v_bfi_b32.  Written as an instruction because the compiler, knowing that only
 // some result bits are read later, splits the expression into more instructions than it saves.
 __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
@@ -162,12 +169,12 @@ struct FastShared {  // small per-workgroup state in static LDS
 };
 
 // Queue entry of a survivor of the rejection test: row << 9 | column << 1 | side, side 1 = ring darker than the
-// centre (a "bright" corner), 0 = ring brighter.
+// centre (a "bright" corner), 0 = ring brighter; step 2 sets bit 15 of the entries it scores as corners.
 // Full segment-test half score of the 64 queue entries [q0, q0 + 64) below q_hi, by one wave.  The side is a lane's
 // own: d_k = (ring_k - centre) * s with s = -1 (ring darker) or +1, one packed multiply-add per pair of ring
 // pixels, so that a wave scores entries of both sides without diverging.
 template <bool RETRY>
-__device__ __forceinline__ void fast_score_wave(const uint8_t* s_tile, uint8_t* s_score, const uint16_t* s_queue,
+__device__ __forceinline__ void fast_score_wave(const uint8_t* s_tile, uint8_t* s_score, uint16_t* s_queue,
                                                 FastShared* sh, int q0, int q_hi, int TP, int SP, int wd, int nc,
                                                 float inv_wcell, int thr, uint16_t* s_corner_top, int corner_room) {
     const int lane = threadIdx.x & 63;
@@ -207,6 +214,7 @@ __device__ __forceinline__ void fast_score_wave(const uint8_t* s_tile, uint8_t* 
                         s_score[(vq + 1) * SP + 1 + u + c] = (uint8_t)(S - 1);
                         hit = true;
                         ke = (c << 14) | (e >> 1);
+                        s_queue[q] = (uint16_t)(e | 0x8000);  // marks the entry as a corner (a pixel is one on one side at most)
                     }
                 }
             }
@@ -258,21 +266,27 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
     // Any arc of 9 holds one pixel of each opposite pair, so a corner needs the two compass pairs
     // (up/down, left/right) and the two diagonal pairs ((+-2, +-2)) to each hold a pixel beyond the threshold
     // on the same side.  (The diagonal pairs halve the survivors, 11.5 % -> 5.7 % of the pixels of a textured
-    // frame against 2.8 % corners, for a third more instructions in the test.)  The
-    // dword's bytes are split into even and odd pixels as two 16-bit lanes; packed u16 min/max
-    // combine the ring pixels of the pairs, and one biased 32-bit subtract per polarity against the
-    // centre moves "beyond the threshold" into bit 15 of each lane.
-    // The eight verdicts of a work item (four pixels, two polarities) go to a byte plane; step 1b turns the
+    // frame against 2.8 % corners, for a third more instructions in the test.)
+    // The test is a filter: it must pass every corner and may pass a few pixels more (step 2 scores the survivors
+    // exactly).  That allows it to run on the dwords as they are, as two 16-bit lanes whose HIGH bytes are the
+    // pixels under test (pixels 1 and 3 of the dword; pixels 0 and 2 after a shift by one byte) and whose low bytes
+    // are whatever pixel lies there: packed u16 min/max order the lanes by the high byte first, so the high byte
+    // of a chain of minima and maxima is that chain on the high bytes, and the low bytes move a difference of
+    // two lanes by less than 256.  centre - max(min(u,d), min(l,r), ...) > t is tested as
+    // lane difference >= 256 t + 1, which holds whenever the exact test does.  Two saturating packed operations
+    // per side turn the comparison into bit 15 of each lane.
+    // The eight verdicts of a work item (four pixels, two sides) go to a byte plane; step 1b turns the
     // plane into the queue.  (Appending to the queue here, with one ballot per verdict, cost as many vector
     // instructions again as the test itself.)
     const int n_items = hd * ndw, vp = fast_verdict_pitch(wd);
-    // the bias that moves "beyond the threshold" into a lane's bit 15 (ring darker) or bit 14 (ring brighter)
-    const uint32_t k_thr = (uint32_t)(0x8000 - 1 - thr) * 0x00010001u, k_thr2 = (uint32_t)(0x4000 - 1 - thr) * 0x00010001u;
+    // bias that moves "difference >= 256 t + 1" into a lane's bit 15 (t above 127 is tested as 127: still a filter)
+    const uint32_t k_bias = (uint32_t)(0x8000 - (256 * min(thr, 127) + 1)) * 0x00010001u;
     // (row, dword) of item tid, advanced by 256 items per iteration without divisions; the item's place in
     // the tile (row v - 3, the dword left of the item's) and in the verdict plane move along by additions
-    int v = (int)(((float)tid + 0.5f) * fast_rcp(ndw));
+    const float inv_ndw = fast_rcp(ndw);
+    int v = (int)(((float)tid + 0.5f) * inv_ndw);
     int j = tid - v * ndw;  // relative to j_lo
-    const int dv = 256 / ndw, dj = 256 - dv * ndw;
+    const int dv = (int)(256.5f * inv_ndw), dj = 256 - dv * ndw;  // 256 / ndw and 256 % ndw
     const uint8_t* pw = s_tile + v * TP + 4 * (j + j_lo);
     uint8_t* pv = s_verdict + v * vp + j + j_lo;
     const int da_t = dv * TP + 4 * dj, da_v = dv * vp + dj, wrap_t = TP - 4 * ndw, wrap_v = vp - ndw;
@@ -280,49 +294,47 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
         uint32_t pb[2], pd[2];  // [0]: bits 15/31 = pixels 0/2, [1]: pixels 1/3
         // items past the end (last iteration only) do nothing
         if (v < hd) {
-            const uint32_t Cd = *reinterpret_cast<const uint32_t*>(pw + 3 * TP + 4);
-            const uint32_t Ud = *reinterpret_cast<const uint32_t*>(pw + 6 * TP + 4);
-            const uint32_t Dd = *reinterpret_cast<const uint32_t*>(pw + 4);
-            // pixels +3 / -3: aligned neighbour dwords shifted into place (unaligned LDS reads are slow)
-            const uint32_t Rd = __builtin_amdgcn_alignbyte(*reinterpret_cast<const uint32_t*>(pw + 3 * TP + 8), Cd, 3);
-            const uint32_t Ld = __builtin_amdgcn_alignbyte(Cd, *reinterpret_cast<const uint32_t*>(pw + 3 * TP), 1);
-            // the two diagonal pairs (ring positions 2/10 and 6/14: pixels (+-2, +-2)) join the test: an arc of 9
-            // holds one pixel of each of them too
+            // the dwords of the item's columns (c), of the four columns before (p) and after (n), rows -3 .. +3
+            const uint32_t Cc = *reinterpret_cast<const uint32_t*>(pw + 3 * TP + 4), Cp = *reinterpret_cast<const uint32_t*>(pw + 3 * TP),
+                           Cn = *reinterpret_cast<const uint32_t*>(pw + 3 * TP + 8);
+            const uint32_t Ud = *reinterpret_cast<const uint32_t*>(pw + 6 * TP + 4), Dd = *reinterpret_cast<const uint32_t*>(pw + 4);
             const uint32_t P2c = *reinterpret_cast<const uint32_t*>(pw + 5 * TP + 4), P2p = *reinterpret_cast<const uint32_t*>(pw + 5 * TP),
                            P2n = *reinterpret_cast<const uint32_t*>(pw + 5 * TP + 8);
             const uint32_t M2c = *reinterpret_cast<const uint32_t*>(pw + TP + 4), M2p = *reinterpret_cast<const uint32_t*>(pw + TP),
                            M2n = *reinterpret_cast<const uint32_t*>(pw + TP + 8);
-            const uint32_t Dpp = __builtin_amdgcn_alignbyte(P2n, P2c, 2), Dmp = __builtin_amdgcn_alignbyte(P2c, P2p, 2);
-            const uint32_t Dpm = __builtin_amdgcn_alignbyte(M2n, M2c, 2), Dmm = __builtin_amdgcn_alignbyte(M2c, M2p, 2);
-            uint32_t on[2] = {0xC000C000u, 0xC000C000u};
+            uint32_t on[2] = {0x80008000u, 0x80008000u};
             if (RETRY) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int u = min(4 * (j + j_lo) + b, wd - 1);
-                    if (sh->th[min((int)(((float)u + 0.5f) * inv_wcell), nc - 1)] < 0) on[b & 1] &= ~(0xC000u << (8 * (b & 2)));
+                    if (sh->th[min((int)(((float)u + 0.5f) * inv_wcell), nc - 1)] < 0) on[b & 1] &= ~(0x8000u << (8 * (b & 2)));
                 }
             }
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {  // 0: pixels 0,2   1: pixels 1,3
-                // one v_perm_b32 spreads two bytes over the 16-bit lanes; the centre takes its bias
-                // (high byte 1) from the second operand
-                const uint32_t sel = h2 ? 0x0C030C01u : 0x0C020C00u;
-                const uint32_t c = __builtin_amdgcn_perm(0u, Cd, sel);
-                const uint32_t u = __builtin_amdgcn_perm(0u, Ud, sel), d = __builtin_amdgcn_perm(0u, Dd, sel);
-                const uint32_t r = __builtin_amdgcn_perm(0u, Rd, sel), l = __builtin_amdgcn_perm(0u, Ld, sel);
-                // ring darker on both pairs: centre - max(min(u,d), min(l,r)) > t; ring brighter:
-                // min(max(u,d), max(l,r)) - centre > t.  With k = 0x8000 - 1 - t added to the minuend the
-                // verdict is bit 15 of each lane, and no lane borrows from its neighbour.
+            for (int h2 = 0; h2 < 2; ++h2) {  // 0: pixels 0, 2   1: pixels 1, 3
+                // every operand is a dword whose bytes 1 and 3 are the ring pixels of the two pixels under test:
+                // v_alignbyte_b32 of two neighbouring dwords (pixels +-3 on the row, +-2 on the rows +-2), the
+                // dword itself or the dword shifted by one byte (centre, rows +-3)
+                uint32_t c, u, d, r, l, pp, mp, pm, mm;
+                if (h2) {
+                    c = Cc, u = Ud, d = Dd;
+                    r = __builtin_amdgcn_alignbyte(Cn, Cc, 3), l = __builtin_amdgcn_alignbyte(Cc, Cp, 1);
+                    pp = __builtin_amdgcn_alignbyte(P2n, P2c, 2), mp = __builtin_amdgcn_alignbyte(P2c, P2p, 2);
+                    pm = __builtin_amdgcn_alignbyte(M2n, M2c, 2), mm = __builtin_amdgcn_alignbyte(M2c, M2p, 2);
+                } else {
+                    c = Cc << 8, u = Ud << 8, d = Dd << 8;
+                    r = __builtin_amdgcn_alignbyte(Cn, Cc, 2), l = Cp;
+                    pp = __builtin_amdgcn_alignbyte(P2n, P2c, 1), mp = __builtin_amdgcn_alignbyte(P2c, P2p, 1);
+                    pm = __builtin_amdgcn_alignbyte(M2n, M2c, 1), mm = __builtin_amdgcn_alignbyte(M2c, M2p, 1);
+                }
+                // ring darker on all four pairs: centre - max(min(u,d), min(l,r), min(pp,mm), min(pm,mp)) > t;
+                // ring brighter: min(max(u,d), ...) - centre > t
                 uint32_t hi = pk_max_u16(pk_min_u16(u, d), pk_min_u16(l, r));
                 uint32_t lo = pk_min_u16(pk_max_u16(u, d), pk_max_u16(l, r));
-                {
-                    const uint32_t pp = __builtin_amdgcn_perm(0u, Dpp, sel), mm = __builtin_amdgcn_perm(0u, Dmm, sel);
-                    const uint32_t pm = __builtin_amdgcn_perm(0u, Dpm, sel), mp = __builtin_amdgcn_perm(0u, Dmp, sel);
-                    hi = pk_max_u16(hi, pk_max_u16(pk_min_u16(pp, mm), pk_min_u16(pm, mp)));
-                    lo = pk_min_u16(lo, pk_min_u16(pk_max_u16(pp, mm), pk_max_u16(pm, mp)));
-                }
-                pb[h2] = (c + k_thr) - hi;   // only bits 15 and 31 are read
-                pd[h2] = (lo + k_thr2) - c;  // only bits 14 and 30 are read
+                hi = pk_max_u16(hi, pk_max_u16(pk_min_u16(pp, mm), pk_min_u16(pm, mp)));
+                lo = pk_min_u16(lo, pk_min_u16(pk_max_u16(pp, mm), pk_max_u16(pm, mp)));
+                pb[h2] = pk_add_sat_u16(pk_sub_sat_u16(c, hi), k_bias);  // only bits 15 and 31 are read
+                pd[h2] = pk_add_sat_u16(pk_sub_sat_u16(lo, c), k_bias);
                 if (RETRY) {
                     pb[h2] &= on[h2];
                     pd[h2] &= on[h2];
@@ -333,7 +345,7 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
             // fold the four bit pairs into the low byte (the other bits of the operands are never read).
             const uint32_t Bm = __builtin_amdgcn_perm(pb[1], pb[0], 0x01050307u);
             const uint32_t Dm = __builtin_amdgcn_perm(pd[1], pd[0], 0x01050307u);
-            uint32_t t = bfi(0x80808080u, Bm, Dm);     // bits 7, 6 of every byte
+            uint32_t t = bfi(0x80808080u, Bm, Dm >> 1);  // bits 7, 6 of every byte
             t = bfi(0xC0C0C0C0u, t, t >> 10);          // bytes 0 and 2: pairs at bits 7..4
             t = bfi(0x000000F0u, t, t >> 20);          // byte 0: all four pairs
             *pv = (uint8_t)t;
@@ -490,31 +502,19 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
     }
     for (int q0 = 0; q0 < qn; q0 += 256) {
         const int q = q0 + tid;
-        bool keep = false, darker = false;
+        bool keep = false;
         int ke = 0, c = 0;
         if (q < qn) {
-            const int e = s_queue[q], u = (e >> 1) & 0xFF, vq = e >> 9;
-            darker = e & 1;
-            if (u < wd) {
+            const int e = s_queue[q], u = (e >> 1) & 0xFF, vq = (e >> 9) & 0x3F;
+            if (e & 0x8000) {  // step 2 found a corner on this entry's side: no pixel is listed twice
                 c = min((int)(((float)u + 0.5f) * inv_wcell), nc - 1);
                 const uint8_t* sp = s_score + (vq + 1) * SP + 1 + u + c;
                 const int sc = sp[0];
-                if (sc > 0) {
-                    const int m = max(max(max((int)sp[-1], (int)sp[1]), max((int)sp[-SP - 1], (int)sp[-SP])),
-                                      max(max((int)sp[-SP + 1], (int)sp[SP - 1]), max((int)sp[SP], (int)sp[SP + 1])));
-                    keep = sc > m;
-                    ke = (c << 14) | (e >> 1);
-                }
+                const int m = max(max(max((int)sp[-1], (int)sp[1]), max((int)sp[-SP - 1], (int)sp[-SP])),
+                                  max(max((int)sp[-SP + 1], (int)sp[SP - 1]), max((int)sp[SP], (int)sp[SP + 1])));
+                keep = sc > m;
+                ke = (c << 14) | ((e & 0x7FFF) >> 1);
             }
-        }
-        // a pixel queued on both sides is listed once: the "ring brighter" entry is dropped when the other exists
-        if (keep && !darker) {
-            const uint8_t* p = s_tile + ((ke >> 8 & 0x3F) + 3) * TP + 4 + (ke & 0xFF);
-            const int cv = p[0];
-            const bool also_front = min(min(max(cv - (int)p[3 * TP], cv - (int)p[-3 * TP]), max(cv - (int)p[3], cv - (int)p[-3])),
-                                        min(max(cv - (int)p[2 * TP + 2], cv - (int)p[-2 * TP - 2]),
-                                            max(cv - (int)p[-2 * TP + 2], cv - (int)p[2 * TP - 2]))) > thr;
-            keep = !also_front;
         }
         const uint64_t m = __ballot(keep);
         if (m) {
@@ -591,28 +591,31 @@ __global__ __launch_bounds__(256) void k_fast_tiles(BatchDev B, const TileDesc* 
 
     // stage the tile: 16-byte chunk c of an LDS row <- the 16 (unaligned) global bytes at
     // x_left + 16c.  All of a thread's loads are issued before the first LDS write, so a tile
-    // costs one memory round trip, not one per chunk.
+    // costs one memory round trip, not one per chunk.  The loads go through a buffer resource over the frame's
+    // level: a 32-bit offset per lane (24-bit multiply-adds) instead of 64-bit address arithmetic.
     {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, L.h * L.pitch, 0x00020000);
         const int nch = fast_tile_pitch(wd) >> 4, total = rows * nch;  // the chunks the tile needs, whatever the pitch
         const int row_end = L.pitch - 16;  // last chunk start that keeps the load inside the row
         const float inv_nch = fast_rcp(nch);
         for (int i0 = 0; i0 < total; i0 += 256 * kFastStageDepth) {
-            uint4 reg[kFastStageDepth];
+            u32x4 reg[kFastStageDepth];
             int dst[kFastStageDepth];
 #pragma unroll
             for (int k = 0; k < kFastStageDepth; ++k) {
                 const int i = i0 + 256 * k + tid;
                 dst[k] = -1;
                 if (i < total) {
-                    const int r = (int)(((float)i + 0.5f) * inv_nch), c = i - r * nch;
+                    const int r = (int)(((float)i + 0.5f) * inv_nch), c = i - __mul24(r, nch);
                     const int col = min(x_left + 16 * c, row_end);
-                    reg[k] = *reinterpret_cast<const uint4_unaligned*>(img + (uint64_t)(y_top + r) * L.pitch + col);
-                    dst[k] = r * TP + 16 * c;
+                    reg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, __mul24(y_top + r, L.pitch) + col, 0, 0);
+                    dst[k] = __mul24(r, TP) + 16 * c;
                 }
             }
 #pragma unroll
             for (int k = 0; k < kFastStageDepth; ++k)
-                if (dst[k] >= 0) *reinterpret_cast<uint4*>(&s_tile[dst[k]]) = reg[k];
+                if (dst[k] >= 0) *reinterpret_cast<u32x4*>(&s_tile[dst[k]]) = reg[k];
         }
     }
     for (int i = tid; i < plane_bytes >> 2; i += 256) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
