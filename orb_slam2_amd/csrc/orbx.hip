@@ -72,7 +72,7 @@ struct DevBuf {
 }  // namespace
 
 enum {  // timing events of one batch
-    kEvPyr0, kEvPyr1, kEvFastA0, kEvFastA1, kEvFastB0, kEvFastB1, kEvOct1, kEvBlur0, kEvBlur1, kEvDesc0, kEvDesc1, kEvCount
+    kEvPyr0, kEvPyr1, kEvFastA0, kEvFastA1, kEvFastB0, kEvFastB1, kEvOct0, kEvOct1, kEvBlur0, kEvBlur1, kEvDesc0, kEvDesc1, kEvCount
 };
 
 struct orbx_ctx {
@@ -103,10 +103,12 @@ struct orbx_ctx {
     // Two sets of everything the descriptor stage reads (pyramid, blurred pyramid, retained points):
     // the descriptors of one batch run while the next batch is detected into the other set.
     DevBuf d_pyr[2], d_blur[2], d_lvl_kps[2], d_lvl_count[2];
-    DevBuf d_cand, d_ccount, d_dense_pts, d_dense_node;
+    DevBuf d_cand[2], d_ccount[2];  // FAST output, alternating like the retained points (index kp_set)
+    DevBuf d_dense_pts, d_dense_node;
     int arena_set = 0, kp_set = 0;            // sets of the last batch
     int arena_desc[2] = {-1, -1};             // descriptor event (index into ev_desc) last reading each arena set
     bool desc_pending[2] = {false, false};    // ev_desc[i] recorded and not yet joined
+    bool oct_pending[2] = {false, false};     // ev_oct_set[i] recorded and not yet joined
     DevBuf d_out_kps, d_out_desc, d_out_n;  // results of the host-memory entry points
     DevBuf d_stamps;                        // diagnostic builds (-DORBX_STAMPS)
 
@@ -132,7 +134,8 @@ struct orbx_ctx {
     // auxiliary compute stream (pyramid + blur beside FAST + quadtree) and its ordering events
     hipStream_t st_aux = nullptr;
     hipStream_t st_desc = nullptr;            // descriptor stage
-    hipEvent_t ev_start, ev_pyr_done, ev_fast_done, ev_blur_done, ev_oct_done, ev_desc[2];
+    hipStream_t st_oct = nullptr;             // quadtree stage
+    hipEvent_t ev_start, ev_pyr_done, ev_fast_done, ev_blur_done, ev_oct_done, ev_desc[2], ev_oct_set[2];
     bool aux_made = false;
     int tiles_level0 = 0;  // the first tiles_level0 entries of `tiles` belong to level 0
     // stereo stage scratch (grown on demand)
@@ -177,6 +180,7 @@ int join(orbx_ctx* c) {
         if (c->desc_pending[i]) {
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_desc[i], 0));
             c->desc_pending[i] = false;
+            c->oct_pending[i] = false;  // a batch's descriptors run after its quadtree
         }
     return ORBX_OK;
 }
@@ -401,8 +405,10 @@ int ensure_arenas(orbx_ctx* c, int n, bool need_level0) {
         if ((rc = ensure(c, &c->d_lvl_kps[k], (size_t)n * c->kp_total * 4))) return rc;
         if ((rc = ensure(c, &c->d_lvl_count[k], (size_t)n * c->tab.nlevels * 4))) return rc;
     }
-    if ((rc = ensure(c, &c->d_cand, (size_t)n * c->total_cells * c->cell_cap * 4))) return rc;
-    if ((rc = ensure(c, &c->d_ccount, (size_t)n * c->total_cells * 4))) return rc;
+    for (int k = 0; k < 2; ++k) {
+        if ((rc = ensure(c, &c->d_cand[k], (size_t)n * c->total_cells * c->cell_cap * 4))) return rc;
+        if ((rc = ensure(c, &c->d_ccount[k], (size_t)n * c->total_cells * 4))) return rc;
+    }
     if ((rc = ensure(c, &c->d_dense_pts, (size_t)n * c->dense_total * 4))) return rc;
     if ((rc = ensure(c, &c->d_dense_node, (size_t)n * c->dense_total * 2))) return rc;
     return ORBX_OK;
@@ -487,6 +493,9 @@ int ensure_aux_streams(orbx_ctx* c) {
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_oct_done, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_desc[0], hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_desc[1], hipEventDisableTiming));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->st_oct, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_oct_set[0], hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_oct_set[1], hipEventDisableTiming));
     c->aux_made = true;
     return ORBX_OK;
 }
@@ -528,12 +537,12 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
             const dim3 grid = fm ? dim3(8, (unsigned)count, (unsigned)((n + 7) / 8)) : dim3((unsigned)count, n);
             if (c->fast_fixed_pitch)
                 hipLaunchKernelGGL(k_fast_tiles<kFastFixedPitch>, grid, dim3(256), c->fast_lds, st, B,
-                                   (const TileDesc*)c->d_tiles.p + first, (uint32_t*)c->d_cand.p, (uint32_t*)c->d_ccount.p,
+                                   (const TileDesc*)c->d_tiles.p + first, (uint32_t*)c->d_cand[kp_set].p, (uint32_t*)c->d_ccount[kp_set].p,
                                    c->fast_tile_bytes, c->fast_plane_bytes, c->fast_queue_bytes, c->fast_kept_bytes,
                                    c->fast_verdict_bytes, fm ? 1 : 0);
             else
                 hipLaunchKernelGGL(k_fast_tiles<0>, grid, dim3(256), c->fast_lds, st, B,
-                                   (const TileDesc*)c->d_tiles.p + first, (uint32_t*)c->d_cand.p, (uint32_t*)c->d_ccount.p,
+                                   (const TileDesc*)c->d_tiles.p + first, (uint32_t*)c->d_cand[kp_set].p, (uint32_t*)c->d_ccount[kp_set].p,
                                    c->fast_tile_bytes, c->fast_plane_bytes, c->fast_queue_bytes, c->fast_kept_bytes,
                                    c->fast_verdict_bytes, fm ? 1 : 0);
         }
@@ -575,7 +584,9 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     if (overlap) {
         HIP_TRY(c, hipEventRecord(c->ev_pyr_done, aux));
     }
-    // stage 1 (main): FAST cells, level 0 first
+    // stage 1 (main): FAST cells, level 0 first.  It overwrites the candidate lists of set kp_set, which the
+    // quadtree of the batch before the previous one may still be reading.
+    if (overlap && c->oct_pending[kp_set]) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_oct_set[kp_set], 0));
     if ((rc = mark(kEvFastA0, st))) return rc;
     launch_fast(0, overlap ? n_tiles0 : 0);
     if ((rc = mark(kEvFastA1, st))) return rc;
@@ -594,19 +605,28 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
         if ((rc = mark(kEvBlur1, aux))) return rc;
         HIP_TRY(c, hipEventRecord(c->ev_blur_done, aux));
     }
-    // stage 2 (main): quadtree retention; it overwrites the retained points of set kp_set, which the
-    // descriptor stage of the batch before the previous one may still be reading
-    if (overlap && c->desc_pending[kp_set]) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_desc[kp_set], 0));
-    hipLaunchKernelGGL(k_octree, dim3(n, L), dim3(256), c->oct_lds, st, B, (const uint32_t*)c->d_cand.p,
-                       (const uint32_t*)c->d_ccount.p, (uint32_t*)c->d_dense_pts.p, (uint16_t*)c->d_dense_node.p,
+    // stage 2: quadtree retention, on a stream of its own so that the next batch's FAST (which writes the other
+    // set of candidate lists) starts beside it: the quadtree is bound by latency and leaves the vector units to
+    // FAST.  It overwrites the retained points of set kp_set, which the descriptor stage of the batch before the
+    // previous one may still be reading.
+    hipStream_t so = overlap ? c->st_oct : st;
+    if (overlap) {
+        HIP_TRY(c, hipStreamWaitEvent(so, c->ev_fast_done, 0));
+        if (c->desc_pending[kp_set]) HIP_TRY(c, hipStreamWaitEvent(so, c->ev_desc[kp_set], 0));
+    }
+    if ((rc = mark(kEvOct0, so))) return rc;
+    hipLaunchKernelGGL(k_octree, dim3(n, L), dim3(256), c->oct_lds, so, B, (const uint32_t*)c->d_cand[kp_set].p,
+                       (const uint32_t*)c->d_ccount[kp_set].p, (uint32_t*)c->d_dense_pts.p, (uint16_t*)c->d_dense_node.p,
                        (uint32_t*)c->d_lvl_kps[kp_set].p, (int32_t*)c->d_lvl_count[kp_set].p);
-    if ((rc = mark(kEvOct1, st))) return rc;
+    if ((rc = mark(kEvOct1, so))) return rc;
     hipStream_t sd = st;  // stream of the descriptor stage
     if (overlap) {
         // stage 4 on its own stream, after the quadtree and the blur; the other streams are then free
         // for the next batch (join() orders anything that needs this batch's results behind it)
         sd = c->st_desc;
-        HIP_TRY(c, hipEventRecord(c->ev_oct_done, st));
+        HIP_TRY(c, hipEventRecord(c->ev_oct_done, so));
+        HIP_TRY(c, hipEventRecord(c->ev_oct_set[kp_set], so));
+        c->oct_pending[kp_set] = true;
         HIP_TRY(c, hipStreamWaitEvent(sd, c->ev_oct_done, 0));
         HIP_TRY(c, hipStreamWaitEvent(sd, c->ev_blur_done, 0));
     } else {
@@ -885,6 +905,7 @@ int build_graph(orbx_ctx* c, int width, int height, int cap) {
     const hipError_t e_end = hipStreamEndCapture(c->stream, &graph);
     c->capturing = false;
     c->desc_pending[0] = c->desc_pending[1] = false;
+    c->oct_pending[0] = c->oct_pending[1] = false;
     c->arena_desc[0] = c->arena_desc[1] = -1;
     c->have_last = false;  // nothing has run yet
     if (rc == ORBX_OK && e_end != hipSuccess) {
@@ -1033,7 +1054,7 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
     }
 #endif
     DevBuf* bufs[] = {&c->d_cells, &c->d_tiles, &c->d_pat, &c->d_pyr[0], &c->d_pyr[1], &c->d_blur[0], &c->d_blur[1],
-                      &c->d_cand, &c->d_ccount, &c->d_dense_pts, &c->d_dense_node, &c->d_lvl_kps[0], &c->d_lvl_kps[1],
+                      &c->d_cand[0], &c->d_cand[1], &c->d_ccount[0], &c->d_ccount[1], &c->d_dense_pts, &c->d_dense_node, &c->d_lvl_kps[0], &c->d_lvl_kps[1],
                       &c->d_lvl_count[0], &c->d_lvl_count[1], &c->d_out_kps,
                       &c->d_out_desc, &c->d_out_n, &c->d_stamps, &c->d_proj_minq, &c->d_proj_state, &c->d_proj_list, &c->d_proj_cache, &c->d_proj_ncache, &c->d_local_pick, &c->d_st_rows, &c->d_st_meta, &c->d_st_wmax,
                       &c->d_st_sad, &c->d_st_u, &c->d_st_depth};
@@ -1051,6 +1072,9 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
         (void)hipEventDestroy(c->ev_oct_done);
         (void)hipEventDestroy(c->ev_desc[0]);
         (void)hipEventDestroy(c->ev_desc[1]);
+        (void)hipEventDestroy(c->ev_oct_set[0]);
+        (void)hipEventDestroy(c->ev_oct_set[1]);
+        (void)hipStreamDestroy(c->st_oct);
         (void)hipStreamDestroy(c->st_desc);
         (void)hipStreamDestroy(c->st_aux);
     }
@@ -1574,13 +1598,13 @@ extern "C" int orbx_debug_read(orbx_ctx* c, int what, int img_idx, int level, vo
     if (what == ORBX_DBG_CANDIDATES) {
         std::vector<uint32_t> cnt(D.n_cells);
         const size_t slot0 = (size_t)img_idx * B.total_cells + D.cell_base;
-        HIP_TRY(c, hipMemcpy(cnt.data(), (uint32_t*)c->d_ccount.p + slot0, (size_t)D.n_cells * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(cnt.data(), (uint32_t*)c->d_ccount[c->kp_set].p + slot0, (size_t)D.n_cells * 4, hipMemcpyDeviceToHost));
         size_t total = 0;
         for (uint32_t v : cnt) total += v;
         *n_bytes = total * 12;
         if (cap_bytes < *n_bytes) return ORBX_E_CAPACITY;
         std::vector<uint32_t> all((size_t)D.n_cells * B.cell_cap);
-        HIP_TRY(c, hipMemcpy(all.data(), (uint32_t*)c->d_cand.p + slot0 * B.cell_cap, all.size() * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(all.data(), (uint32_t*)c->d_cand[c->kp_set].p + slot0 * B.cell_cap, all.size() * 4, hipMemcpyDeviceToHost));
         int32_t* o = (int32_t*)dst;
         for (int k = 0; k < D.n_cells; ++k)
             for (uint32_t j = 0; j < cnt[k]; ++j) {
@@ -1651,7 +1675,7 @@ extern "C" int orbx_get_stage_ms(orbx_ctx* c, float ms[ORBX_NUM_STAGES]) {
     if ((rc = span(kEvFastA0, kEvFastA1, &fa))) return rc;
     if ((rc = span(kEvFastB0, kEvFastB1, &fb))) return rc;
     ms[1] = fa + fb;
-    if ((rc = span(kEvFastB1, kEvOct1, &ms[2]))) return rc;
+    if ((rc = span(kEvOct0, kEvOct1, &ms[2]))) return rc;
     if ((rc = span(kEvBlur0, kEvBlur1, &ms[3]))) return rc;
     if ((rc = span(kEvDesc0, kEvDesc1, &ms[4]))) return rc;
     return ORBX_OK;
