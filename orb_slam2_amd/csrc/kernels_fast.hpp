@@ -396,6 +396,16 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
             base = __builtin_amdgcn_readfirstlane(base);
             if (base + tot > q_cap) continue;  // wave-uniform
             uint16_t* q_p = s_queue + base + (incl - cnt);
+            // eight hits per lane with the slot as an instruction offset, then whatever is left
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                if (!__builtin_amdgcn_ballot_w64(w != 0)) break;
+                if (w) {
+                    q_p[n] = (uint16_t)(ebase + __builtin_ctz(w));
+                    w &= w - 1;
+                }
+            }
+            q_p += 8;
             while (__builtin_amdgcn_ballot_w64(w != 0)) {
                 if (w) {
                     *q_p++ = (uint16_t)(ebase + __builtin_ctz(w));
