@@ -284,16 +284,17 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
     // (row, dword) of item tid, advanced by 256 items per iteration without divisions; the item's place in
     // the tile (row v - 3, the dword left of the item's) and in the verdict plane move along by additions
     const float inv_ndw = fast_rcp(ndw);
-    int v = (int)(((float)tid + 0.5f) * inv_ndw);
-    int j = tid - v * ndw;  // relative to j_lo
+    const int v0 = (int)(((float)tid + 0.5f) * inv_ndw);
+    int j = tid - v0 * ndw;  // relative to j_lo
     const int dv = (int)(256.5f * inv_ndw), dj = 256 - dv * ndw;  // 256 / ndw and 256 % ndw
-    const uint8_t* pw = s_tile + v * TP + 4 * (j + j_lo);
-    uint8_t* pv = s_verdict + v * vp + j + j_lo;
-    const int da_t = dv * TP + 4 * dj, da_v = dv * vp + dj, wrap_t = TP - 4 * ndw, wrap_v = vp - ndw;
+    const uint8_t* pw = s_tile + v0 * TP + 4 * (j + j_lo);
+    uint8_t* pv = s_verdict + v0 * vp + j + j_lo;
+    // steps of the two places: without and with a wrap into the next row (selected per lane, no branch)
+    const int da_t = dv * TP + 4 * dj, da_v = dv * vp + dj, da_tw = da_t + TP - 4 * ndw, da_vw = da_v + vp - ndw;
     for (int i0 = 0; i0 < n_items; i0 += 256) {
         uint32_t pb[2], pd[2];  // [0]: bits 15/31 = pixels 0/2, [1]: pixels 1/3
         // items past the end (last iteration only) do nothing
-        if (v < hd) {
+        if (tid < n_items - i0) {
             // the dwords of the item's columns (c), of the four columns before (p) and after (n), rows -3 .. +3
             const uint32_t Cc = *reinterpret_cast<const uint32_t*>(pw + 3 * TP + 4), Cp = *reinterpret_cast<const uint32_t*>(pw + 3 * TP),
                            Cn = *reinterpret_cast<const uint32_t*>(pw + 3 * TP + 8);
@@ -350,16 +351,11 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
             t = bfi(0x000000F0u, t, t >> 20);          // byte 0: all four pairs
             *pv = (uint8_t)t;
         }
-        v += dv;
         j += dj;
-        pw += da_t;
-        pv += da_v;
-        if (j >= ndw) {
-            j -= ndw;
-            ++v;
-            pw += wrap_t;
-            pv += wrap_v;
-        }
+        const bool wrap = j >= ndw;
+        j -= wrap ? ndw : 0;
+        pw += wrap ? da_tw : da_t;
+        pv += wrap ? da_vw : da_v;
     }
     __syncthreads();
     // ---- 1b. the verdict plane becomes the queue ----
