@@ -305,6 +305,55 @@ __host__ __device__ inline int blur_main_blocks(int w, int h) {
 }
 __host__ __device__ inline int blur_edge_blocks(int h) { return (h + kBlurEdgeRows - 1) / kBlurEdgeRows; }
 
+// The streaming part of k_blur7_all for one lane: walks down the lane's row tile.  INNER: every source row of
+// the tile lies inside the image (see the call).
+template <bool INNER>
+__device__ __forceinline__ void blur_stream(const __amdgpu_buffer_rsrc_t rs, const __amdgpu_buffer_rsrc_t rd, int y0, int h,
+                                            int spitch, int dpitch, int vcol, int x0, bool store_ok) {
+    const int kOut = 0x7FFFFFF0;
+    // INNER: offsets of the tile's first source row and first output dword (unsigned: a lane with nothing to
+    // load or store starts at kOut and stays out of the buffer's range)
+    const uint32_t vbase = (uint32_t)((y0 - 3) * spitch) + (uint32_t)vcol;
+    const uint32_t sbase = store_ok ? (uint32_t)(y0 * dpitch + x0) : (uint32_t)kOut;
+    uint32_t qC[kBlurPF];
+#pragma unroll
+    for (int r = 0; r < kBlurPF; ++r) {
+        const int vo = INNER ? (int)(vbase + (uint32_t)(r * spitch)) : reflect101(min(y0 + r - 3, h + 2), h) * spitch + vcol;
+        qC[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0, 0);
+    }
+    uint32_t pr[6][4], wp[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < kBlurRows + 6; ++r) {
+        const uint32_t C = qC[r % kBlurPF];
+        const uint32_t Lw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x138, 0xF, 0xF, false);  // lane - 1
+        const uint32_t R = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x130, 0xF, 0xF, false);   // lane + 1
+        if (r + kBlurPF < kBlurRows + 6) {
+            const int vo = INNER ? (int)(vbase + (uint32_t)((r + kBlurPF) * spitch)) : reflect101(min(y0 + r + kBlurPF - 3, h + 2), h) * spitch + vcol;
+            qC[r % kBlurPF] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0, 0);
+        }
+        const uint32_t a0 = __builtin_amdgcn_alignbyte(C, Lw, 1), b0 = __builtin_amdgcn_alignbyte(R, C, 1);
+        const uint32_t a1 = __builtin_amdgcn_alignbyte(C, Lw, 2), b1 = __builtin_amdgcn_alignbyte(R, C, 2);
+        const uint32_t a2 = __builtin_amdgcn_alignbyte(C, Lw, 3), b2 = __builtin_amdgcn_alignbyte(R, C, 3);
+        uint32_t wr[4];
+        wr[0] = __builtin_amdgcn_udot4(b0, 0x00122231u, __builtin_amdgcn_udot4(a0, 0x37312212u, 0u, false), false);
+        wr[1] = __builtin_amdgcn_udot4(b1, 0x00122231u, __builtin_amdgcn_udot4(a1, 0x37312212u, 0u, false), false);
+        wr[2] = __builtin_amdgcn_udot4(b2, 0x00122231u, __builtin_amdgcn_udot4(a2, 0x37312212u, 0u, false), false);
+        wr[3] = __builtin_amdgcn_udot4(R, 0x00122231u, __builtin_amdgcn_udot4(C, 0x37312212u, 0u, false), false);
+        if (r >= 6) {
+            const int y = y0 + r - 6;
+            const uint32_t o = blur_pack(blur_col(pr, wr[0], r, 0), blur_col(pr, wr[1], r, 1), blur_col(pr, wr[2], r, 2),
+                                         blur_col(pr, wr[3], r, 3));
+            const int vs = INNER ? (int)(sbase + (uint32_t)((r - 6) * dpitch)) : ((store_ok && y < h) ? y * dpitch + x0 : kOut);
+            __builtin_amdgcn_raw_buffer_store_b32(o, rd, vs, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (r >= 1) pr[(r + 5) % 6][k] = __builtin_amdgcn_perm(wr[k], wp[k], 0x05040100u);  // rows (r-1, r)
+            wp[k] = wr[k];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_blur7_all(BatchDev B, int frame_major) {
     const int blk_all = frame_major ? blockIdx.y : blockIdx.x;
     const int frame = frame_major ? blockIdx.z * gridDim.x + blockIdx.x : blockIdx.y;
@@ -371,43 +420,14 @@ __global__ __launch_bounds__(256) void k_blur7_all(BatchDev B, int frame_major) 
     // stores: those columns belong to the edge blocks.
     const bool store_ok = live && x0 >= 4 && x0 <= last_full && lane >= 1 && lane <= 62;
     const int vcol = live ? x0 : kOut;
-    uint32_t qC[kBlurPF];
-#pragma unroll
-    for (int r = 0; r < kBlurPF; ++r) {
-        const int vo = reflect101(min(y0 + r - 3, h + 2), h) * spitch + vcol;
-        qC[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0, 0);
-    }
-    uint32_t pr[6][4], wp[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int r = 0; r < kBlurRows + 6; ++r) {
-        const uint32_t C = qC[r % kBlurPF];
-        const uint32_t Lw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x138, 0xF, 0xF, false);  // lane - 1
-        const uint32_t R = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x130, 0xF, 0xF, false);   // lane + 1
-        if (r + kBlurPF < kBlurRows + 6) {
-            const int vo = reflect101(min(y0 + r + kBlurPF - 3, h + 2), h) * spitch + vcol;
-            qC[r % kBlurPF] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0, 0);
-        }
-        const uint32_t a0 = __builtin_amdgcn_alignbyte(C, Lw, 1), b0 = __builtin_amdgcn_alignbyte(R, C, 1);
-        const uint32_t a1 = __builtin_amdgcn_alignbyte(C, Lw, 2), b1 = __builtin_amdgcn_alignbyte(R, C, 2);
-        const uint32_t a2 = __builtin_amdgcn_alignbyte(C, Lw, 3), b2 = __builtin_amdgcn_alignbyte(R, C, 3);
-        uint32_t wr[4];
-        wr[0] = __builtin_amdgcn_udot4(b0, 0x00122231u, __builtin_amdgcn_udot4(a0, 0x37312212u, 0u, false), false);
-        wr[1] = __builtin_amdgcn_udot4(b1, 0x00122231u, __builtin_amdgcn_udot4(a1, 0x37312212u, 0u, false), false);
-        wr[2] = __builtin_amdgcn_udot4(b2, 0x00122231u, __builtin_amdgcn_udot4(a2, 0x37312212u, 0u, false), false);
-        wr[3] = __builtin_amdgcn_udot4(R, 0x00122231u, __builtin_amdgcn_udot4(C, 0x37312212u, 0u, false), false);
-        if (r >= 6) {
-            const int y = y0 + r - 6;
-            const uint32_t o = blur_pack(blur_col(pr, wr[0], r, 0), blur_col(pr, wr[1], r, 1), blur_col(pr, wr[2], r, 2),
-                                         blur_col(pr, wr[3], r, 3));
-            const int vs = (store_ok && y < h) ? y * dpitch + x0 : kOut;
-            __builtin_amdgcn_raw_buffer_store_b32(o, rd, vs, 0, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (r >= 1) pr[(r + 5) % 6][k] = __builtin_amdgcn_perm(wr[k], wp[k], 0x05040100u);  // rows (r-1, r)
-            wp[k] = wr[k];
-        }
-    }
+    // Row tiles whose 38 source rows all lie inside the image need no reflection and no row checks: their row
+    // offsets are the lane's first offset plus a scalar multiple of the pitch (about a fifth fewer vector
+    // instructions).  The choice is made per wave; idle lanes go along with either path.
+    const bool inner = !live || (y0 >= 3 && y0 + kBlurRows + 2 < h);
+    if (__builtin_amdgcn_ballot_w64(!inner) == 0)
+        blur_stream<true>(rs, rd, y0, h, spitch, dpitch, vcol, x0, store_ok);
+    else
+        blur_stream<false>(rs, rd, y0, h, spitch, dpitch, vcol, x0, store_ok);
 }
 
 }  // namespace orbx
