@@ -24,16 +24,39 @@ namespace orbx {
 
 constexpr uint32_t kNoSplit = 0xFFFFFFFFu;
 constexpr int kPtBatch = 8;  // global loads in flight per thread in the loops over the points
+constexpr int kOctWideFrom = 1000;  // levels that keep more features than this get 1024 threads
 
-// In-place exclusive scan of a[0..n) in LDS by 256 threads; returns the total.
+// Block-wide exclusive scan of one int per thread (NT threads = NT / 64 waves).
+// Returns the exclusive prefix; *total receives the block sum.  Contains two barriers.
+template <int NT>
+__device__ __forceinline__ int block_excl_scan(int v, int* s_wave, int* total) {
+    constexpr int NW = NT / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int incl = wave_incl_scan(v);
+    __syncthreads();  // protects s_wave against a previous use
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int t = s_wave[k];
+        if (k < wave) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+// In-place exclusive scan of a[0..n) in LDS by NT threads; returns the total.
 // Thread t owns the run [t*per, (t+1)*per).
+template <int NT>
 __device__ __forceinline__ uint32_t lds_excl_scan(uint32_t* a, int n, int* s_wave4) {
-    const int per = (n + 255) >> 8;
+    const int per = (n + NT - 1) / NT;
     const int beg = min((int)threadIdx.x * per, n), end = min(beg + per, n);
     uint32_t sum = 0;
     for (int i = beg; i < end; ++i) sum += a[i];
     int total;
-    uint32_t run = (uint32_t)block_excl_scan_256((int)sum, s_wave4, &total);
+    uint32_t run = (uint32_t)block_excl_scan<NT>((int)sum, s_wave4, &total);
     for (int i = beg; i < end; ++i) {
         const uint32_t v = a[i];
         a[i] = run;
@@ -65,13 +88,15 @@ __host__ __device__ inline size_t oct_lds_bytes(int max_slots, int max_kp, int n
     return (node > pro ? node : pro) + 64;
 }
 
-// grid = (frames, nlevels), block = 256, dynamic LDS = max over levels of oct_lds_bytes.
-__global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __restrict__ cand,
+// grid = (frames, nlevels), block = NT (256, or 1024 for levels of thousands of features), dynamic LDS = max
+// over levels of oct_lds_bytes.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_octree(BatchDev B, const uint32_t* __restrict__ cand,
                                                 const uint32_t* __restrict__ ccount,
                                                 uint32_t* __restrict__ dense_pts, uint16_t* __restrict__ dense_node,
                                                 uint32_t* __restrict__ lvl_kps, int32_t* __restrict__ lvl_count) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
-    __shared__ int s_wave4[4];
+    __shared__ int s_wave4[NT / 64];
     __shared__ int s_i[8];  // 0: jcut, 1: nToExpand, 2: finished, 3: careful
 
     const int tid = threadIdx.x;
@@ -86,10 +111,10 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
     // ---- prologue: gather the level's candidates into a dense array, in cell order ----------
     uint32_t* s_prefix = reinterpret_cast<uint32_t*>(s_raw);
     const uint64_t slot0 = (uint64_t)frame * B.total_cells + L.cell_base;
-    for (int c = tid; c < L.n_cells; c += 256) s_prefix[c] = ccount[slot0 + c];
+    for (int c = tid; c < L.n_cells; c += NT) s_prefix[c] = ccount[slot0 + c];
     if (tid == 0) s_prefix[L.n_cells] = 0;
     __syncthreads();
-    const int C = (int)lds_excl_scan(s_prefix, L.n_cells + 1, s_wave4);
+    const int C = (int)lds_excl_scan<NT>(s_prefix, L.n_cells + 1, s_wave4);
     uint32_t* pts = dense_pts + (uint64_t)frame * B.dense_total + L.dense_off;
     uint16_t* node_of = dense_node + (uint64_t)frame * B.dense_total + L.dense_off;
     int32_t* out_count = lvl_count + (uint64_t)frame * B.nlevels + level;
@@ -100,12 +125,12 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
     const float h_x = L.h_x;
     // Global loads are issued kPtBatch at a time before their first use: the loops over the points
     // are latency-bound, and independent loads in flight divide the number of round trips.
-    for (int p0 = tid; p0 < C; p0 += 256 * kPtBatch) {
+    for (int p0 = tid; p0 < C; p0 += NT * kPtBatch) {
         uint32_t v[kPtBatch];
         uint64_t src[kPtBatch];
 #pragma unroll
         for (int k = 0; k < kPtBatch; ++k) {
-            const int p = min(p0 + 256 * k, C - 1);
+            const int p = min(p0 + NT * k, C - 1);
             int lo = 0, hi = L.n_cells;  // last cell with prefix <= p
             while (hi - lo > 1) {
                 const int m = (lo + hi) >> 1;
@@ -117,7 +142,7 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
         for (int k = 0; k < kPtBatch; ++k) v[k] = cand[src[k]];
 #pragma unroll
         for (int k = 0; k < kPtBatch; ++k) {
-            const int p = p0 + 256 * k;
+            const int p = p0 + NT * k;
             if (p < C) {
                 pts[p] = v[k];
                 int r = (int)((float)pt_x(v[k]) / h_x);  // root of the point (:620)
@@ -151,7 +176,7 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
         T.rank = (uint16_t*)q; q += mk * 2;
         T.proc = (uint16_t*)q; q += mk * 2;
     }
-    for (int s = tid; s < L.max_slots; s += 256) {
+    for (int s = tid; s < L.max_slots; s += NT) {
         T.cnt[s] = 0;
         T.mid[s] = kNoSplit;
         T.best[s] = 0;
@@ -159,16 +184,16 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
     }
     __syncthreads();
     // roots (:585-610): box i = [int(hX*i), int(hX*(i+1))] x [0, H]
-    for (int i = tid; i < L.n_ini; i += 256) {
+    for (int i = tid; i < L.n_ini; i += NT) {
         T.bx0[i] = (uint16_t)(int)(h_x * (float)i);
         T.bx1[i] = (uint16_t)(int)(h_x * (float)(i + 1));
         T.by0[i] = 0;
         T.by1[i] = (uint16_t)L.rect_h;
     }
-    for (int p0 = tid; p0 < C; p0 += 256 * kPtBatch) {
+    for (int p0 = tid; p0 < C; p0 += NT * kPtBatch) {
         int s[kPtBatch];
 #pragma unroll
-        for (int k = 0; k < kPtBatch; ++k) s[k] = p0 + 256 * k < C ? (int)node_of[p0 + 256 * k] : -1;
+        for (int k = 0; k < kPtBatch; ++k) s[k] = p0 + NT * k < C ? (int)node_of[p0 + NT * k] : -1;
 #pragma unroll
         for (int k = 0; k < kPtBatch; ++k)
             if (s[k] >= 0) atomicAdd(&T.cnt[s[k]], 1u);
@@ -193,14 +218,14 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
     uint16_t* ord_new = T.ordB;
 
     // child-quadrant counts of every node with > 1 point
-    for (int p0 = tid; p0 < C; p0 += 256 * kPtBatch) {
+    for (int p0 = tid; p0 < C; p0 += NT * kPtBatch) {
         int sn[kPtBatch];
         uint32_t v[kPtBatch];
 #pragma unroll
         for (int k = 0; k < kPtBatch; ++k) {
-            const bool ok = p0 + 256 * k < C;
-            sn[k] = ok ? (int)node_of[p0 + 256 * k] : -1;
-            v[k] = ok ? pts[p0 + 256 * k] : 0u;
+            const bool ok = p0 + NT * k < C;
+            sn[k] = ok ? (int)node_of[p0 + NT * k] : -1;
+            v[k] = ok ? pts[p0 + NT * k] : 0u;
         }
 #pragma unroll
         for (int k = 0; k < kPtBatch; ++k) {
@@ -223,7 +248,7 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
         // sort key of an expandable node: size, then list position (earlier first); unique, 0 = not expandable.
         // The size field holds 16 bits: larger nodes all carry 0xFFFF there and are told apart by their
         // real counts where the order matters (the ranking of the one-at-a-time phase below).
-        for (int i = tid; i < ((n + 3) & ~3); i += 256) {
+        for (int i = tid; i < ((n + 3) & ~3); i += NT) {
             const uint32_t c = i < n ? T.cnt[ord[i]] : 0u;
             T.key[i] = c > 1 ? (min(c, 0xFFFFu) << 16) | (0xFFFFu - (uint32_t)i) : 0u;
         }
@@ -234,15 +259,15 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
         __syncthreads();
         int n_exp;
         if (!careful) {
-            for (int i = tid; i < n; i += 256) T.scanB[i] = T.key[i] ? 1u : 0u;
+            for (int i = tid; i < n; i += NT) T.scanB[i] = T.key[i] ? 1u : 0u;
             __syncthreads();
-            n_exp = (int)lds_excl_scan(T.scanB, n, s_wave4);
-            for (int i = tid; i < n; i += 256)
+            n_exp = (int)lds_excl_scan<NT>(T.scanB, n, s_wave4);
+            for (int i = tid; i < n; i += NT)
                 if (T.key[i]) T.rank[i] = (uint16_t)T.scanB[i];
         } else {
-            // rank by (size descending, list position ascending): counting rank, O(n^2 / 256)
+            // rank by (size descending, list position ascending): counting rank, O(n^2 / NT)
             int cnt_exp = 0;
-            for (int i = tid; i < n; i += 256) {
+            for (int i = tid; i < n; i += NT) {
                 const uint32_t ki = T.key[i];
                 if (ki) {
                     int r = 0;
@@ -267,12 +292,12 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
                 }
             }
             int tot;
-            block_excl_scan_256(cnt_exp, s_wave4, &tot);
+            block_excl_scan<NT>(cnt_exp, s_wave4, &tot);
             n_exp = tot;
         }
         __syncthreads();
         // per rank: created children | growth << 16
-        for (int i = tid; i < n; i += 256) {
+        for (int i = tid; i < n; i += NT) {
             if (T.key[i]) {
                 const int s = ord[i];
                 const int k = (T.cc[4 * s] ? 1 : 0) + (T.cc[4 * s + 1] ? 1 : 0) + (T.cc[4 * s + 2] ? 1 : 0) +
@@ -286,10 +311,10 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
         // keep inclusive values reachable: scanA becomes exclusive, the element value is re-derived
         // from cc when needed
         uint32_t tot_all = 0;
-        if (n_exp > 0) tot_all = lds_excl_scan(T.scanA, n_exp, s_wave4);
+        if (n_exp > 0) tot_all = lds_excl_scan<NT>(T.scanA, n_exp, s_wave4);
         // cut: first rank whose inclusive growth brings the node count to N (careful phase only)
         if (careful) {
-            for (int r = tid; r < n_exp; r += 256) {
+            for (int r = tid; r < n_exp; r += NT) {
                 const uint32_t incl = (r + 1 < n_exp) ? T.scanA[r + 1] : tot_all;
                 if (n + (int)(incl >> 16) >= N) atomicMin(&s_i[0], r);
             }
@@ -300,13 +325,13 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
         const int created = n_exp > 0 ? (int)(tot_cut & 0xFFFF) : 0;
         const int growth = n_exp > 0 ? (int)(tot_cut >> 16) : 0;
         // stays-in-place flags in list order
-        for (int i = tid; i < n; i += 256) {
+        for (int i = tid; i < n; i += NT) {
             const bool split = T.key[i] && (int)T.rank[i] <= jcut;
             T.scanB[i] = split ? 0u : 1u;
         }
         __syncthreads();
         // split the chosen nodes
-        for (int r = tid; r <= jcut; r += 256) {
+        for (int r = tid; r <= jcut; r += NT) {
             const int i = T.proc[r];
             const int s = ord[i];
             const uint32_t ex = T.scanA[r];
@@ -343,12 +368,12 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
         // (slots are read from `ord`; a re-used slot id in `ord` belongs to a split node and is skipped)
         {
             // flags must be captured before the scan overwrites them
-            const int per = (n + 255) >> 8;
+            const int per = (n + NT - 1) / NT;
             const int beg = min(tid * per, n), end = min(beg + per, n);
             uint32_t keep_mask = 0;  // per <= 32 guaranteed by max_kp <= 8192
             for (int i = beg; i < end; ++i) keep_mask |= (T.scanB[i] ? 1u : 0u) << (i - beg);
             __syncthreads();
-            lds_excl_scan(T.scanB, n, s_wave4);
+            lds_excl_scan<NT>(T.scanB, n, s_wave4);
             for (int i = beg; i < end; ++i)
                 if ((keep_mask >> (i - beg)) & 1u) ord_new[created + (int)T.scanB[i]] = ord[i];
         }
@@ -373,20 +398,20 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
 
         ORBX_STAMP(B, careful ? 11 : 10, t0);
         // ---------------- point step ----------------
-        for (int p0 = tid; p0 < C; p0 += 256 * kPtBatch) {
+        for (int p0 = tid; p0 < C; p0 += NT * kPtBatch) {
             int sn[kPtBatch];
             uint32_t vv[kPtBatch];
 #pragma unroll
             for (int k = 0; k < kPtBatch; ++k) {
-                const bool ok = p0 + 256 * k < C;
-                sn[k] = ok ? (int)node_of[p0 + 256 * k] : -1;
-                vv[k] = ok ? pts[p0 + 256 * k] : 0u;
+                const bool ok = p0 + NT * k < C;
+                sn[k] = ok ? (int)node_of[p0 + NT * k] : -1;
+                vv[k] = ok ? pts[p0 + NT * k] : 0u;
             }
 #pragma unroll
             for (int k = 0; k < kPtBatch; ++k) {
                 int s = sn[k];
                 if (s < 0) continue;
-                const int p = p0 + 256 * k;
+                const int p = p0 + NT * k;
                 const uint32_t v = vv[k];
                 const uint32_t m = T.mid[s];
                 if (m != kNoSplit) {
@@ -409,13 +434,13 @@ __global__ __launch_bounds__(256) void k_octree(BatchDev B, const uint32_t* __re
         __syncthreads();
         ORBX_STAMP(B, 12, t0);
         if (finished) break;
-        for (int s = tid; s < n_slots; s += 256) T.mid[s] = kNoSplit;
+        for (int s = tid; s < n_slots; s += NT) T.mid[s] = kNoSplit;
         __syncthreads();
     }
 
     // ---- output in list order ------------------------------------------------------------------
     uint32_t* out = lvl_kps + (uint64_t)frame * B.kp_total + L.kp_off;
-    for (int i = tid; i < n_alive; i += 256) {
+    for (int i = tid; i < n_alive; i += NT) {
         const uint32_t b = T.best[ord[i]];
         const uint32_t p = 0xFFFFFFu - (b & 0xFFFFFFu);
         out[i] = pts[p];

@@ -615,9 +615,16 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
         if (c->desc_pending[kp_set]) HIP_TRY(c, hipStreamWaitEvent(so, c->ev_desc[kp_set], 0));
     }
     if ((rc = mark(kEvOct0, so))) return rc;
-    hipLaunchKernelGGL(k_octree, dim3(n, L), dim3(256), c->oct_lds, so, B, (const uint32_t*)c->d_cand[kp_set].p,
-                       (const uint32_t*)c->d_ccount[kp_set].p, (uint32_t*)c->d_dense_pts.p, (uint16_t*)c->d_dense_node.p,
-                       (uint32_t*)c->d_lvl_kps[kp_set].p, (int32_t*)c->d_lvl_count[kp_set].p);
+    // 1024 threads per (frame, level) when a level keeps more than a thousand features (the loops over the
+    // points and the rank-by-counting of the nodes are then long), else 256
+    if (c->max_kp_level > kOctWideFrom)
+        hipLaunchKernelGGL(k_octree<1024>, dim3(n, L), dim3(1024), c->oct_lds, so, B, (const uint32_t*)c->d_cand[kp_set].p,
+                           (const uint32_t*)c->d_ccount[kp_set].p, (uint32_t*)c->d_dense_pts.p, (uint16_t*)c->d_dense_node.p,
+                           (uint32_t*)c->d_lvl_kps[kp_set].p, (int32_t*)c->d_lvl_count[kp_set].p);
+    else
+        hipLaunchKernelGGL(k_octree<256>, dim3(n, L), dim3(256), c->oct_lds, so, B, (const uint32_t*)c->d_cand[kp_set].p,
+                           (const uint32_t*)c->d_ccount[kp_set].p, (uint32_t*)c->d_dense_pts.p, (uint16_t*)c->d_dense_node.p,
+                           (uint32_t*)c->d_lvl_kps[kp_set].p, (int32_t*)c->d_lvl_count[kp_set].p);
     if ((rc = mark(kEvOct1, so))) return rc;
     hipStream_t sd = st;  // stream of the descriptor stage
     if (overlap) {
@@ -1015,7 +1022,7 @@ extern "C" int orbx_create(const orbx_params* params, orbx_ctx** out) {
     c->ev_made = true;
     // every context sets the same limit, so a later context cannot lower what an earlier one relies on
     for (const void* fn : {reinterpret_cast<const void*>(k_fast_tiles<0>), reinterpret_cast<const void*>(k_fast_tiles<kFastFixedPitch>),
-                           reinterpret_cast<const void*>(k_octree),
+                           reinterpret_cast<const void*>(k_octree<256>), reinterpret_cast<const void*>(k_octree<1024>),
                            reinterpret_cast<const void*>(k_bow_vectors)})
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds) != hipSuccess)
             return fail(ORBX_E_HIP);
