@@ -808,7 +808,7 @@ int extract_batch_pipelined(orbx_ctx* c, int n, const uint8_t* const* imgs, int 
     if (rc) return rc;
     if ((rc = sync_ctx(c))) return rc;  // nothing of an earlier call is still in flight
     const int aset = c->arena_set ^ 1;
-    const int host_threads = (int)std::max(1u, std::min(4u, std::thread::hardware_concurrency()));
+    const int host_threads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
     const int nchunks = (n + m - 1) / m;
     orbx_kp* d_kps = (orbx_kp*)c->d_out_kps.p;
     uint8_t* d_desc = (uint8_t*)c->d_out_desc.p;
