@@ -310,6 +310,26 @@ int orbx_search_local_map_batch_device(orbx_ctx* ctx, int n, const orbx_kp* d_kp
                                        const orbx_local_query* d_queries, int q_cap, const int32_t* d_nq,
                                        int32_t* d_match, int32_t* d_query_match, int32_t* d_nmatches, int sync);
 
+/* ---- descriptor consumer: matching by vocabulary node -------------------------------------
+ * Replaces ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches) (reference
+ * src/ORBmatcher.cc:159-290; called from Tracking::TrackReferenceKeyFrame, src/Tracking.cc:894, and
+ * Tracking::Relocalization, :1563) for a batch of (keyframe, frame) pairs: for every vocabulary node both
+ * FeatureVectors hold, every keyframe feature with a good map point looks for its best and second best
+ * descriptor distance among the frame's features of that node that no earlier keyframe feature took,
+ * accepts a best distance <= 50 (TH_LOW) below nn_ratio (mfNNratio) times the second, and the rotation
+ * histogram keeps the three main bins when check_orientation is set.  The FeatureVectors are what
+ * orbx_bow_transform_batch_device leaves ((node, feature index) pairs, nodes ascending): pair f reads
+ * d_fv_*_kf[f*kp_cap_kf ..], d_fv_*_f[f*kp_cap_f ..]; d_kps_* supply the angles (pKF->mvKeysUn, F.mvKeys);
+ * d_valid_kf[f*kp_cap_kf + i] != 0 when the keyframe's feature i holds a map point that is not bad.
+ * Outputs: d_match[f*kp_cap_f + k] = index of the keyframe feature whose map point vpMapPointMatches[k]
+ * becomes (-1: NULL), d_nmatches[f] = the return value.  kp_cap_kf, kp_cap_f <= 16384. */
+int orbx_search_by_bow_batch_device(orbx_ctx* ctx, int n, const uint32_t* d_fv_node_kf, const uint32_t* d_fv_idx_kf,
+                                    const int32_t* d_fv_n_kf, const uint8_t* d_desc_kf, const orbx_kp* d_kps_kf,
+                                    const uint8_t* d_valid_kf, int kp_cap_kf, const uint32_t* d_fv_node_f,
+                                    const uint32_t* d_fv_idx_f, const int32_t* d_fv_n_f, const uint8_t* d_desc_f,
+                                    const orbx_kp* d_kps_f, int kp_cap_f, float nn_ratio, int check_orientation,
+                                    int32_t* d_match, int32_t* d_nmatches, int sync);
+
 /* ---- the stage after the extractor: stereo association ---------------------------------
  * Replaces Frame::ComputeStereoMatches (reference src/Frame.cc:485-659, descriptor distance
  * src/ORBmatcher.cc:1684-1700): for every left keypoint the best right keypoint in its row

@@ -1507,3 +1507,78 @@ extern "C" int orc_search_local_map(const float* kps_xy, const int32_t* octave, 
     }
     return nmatches;
 }
+
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (reference src/ORBmatcher.cc:159-290):
+// features of the keyframe and of the frame that fall into the same vocabulary node are matched, node by
+// node.  A FeatureVector comes as (node, feature index) pairs, nodes ascending and indices ascending inside
+// a node (what std::map<NodeId, vector<unsigned>> iterates as); valid_kf[i] != 0: the keyframe's feature i
+// holds a map point that is not bad (:193-197).  match[k] = index of the keyframe feature whose map point
+// frame feature k ends with (-1: none); returns nmatches.
+extern "C" int orc_search_by_bow(const uint32_t* fv_node_kf, const uint32_t* fv_idx_kf, int fv_n_kf, const uint8_t* desc_kf,
+                                 const float* angle_kf, const uint8_t* valid_kf, const uint32_t* fv_node_f,
+                                 const uint32_t* fv_idx_f, int fv_n_f, const uint8_t* desc_f, const float* angle_f, int n_f,
+                                 float nn_ratio, int check_orientation, int32_t* match) {
+    const int HISTO_LENGTH = 30, TH_LOW = 50;
+    for (int i = 0; i < n_f; i++) match[i] = -1;  // :163
+    int nmatches = 0;
+    std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+    const float factor = 1.0f / HISTO_LENGTH;  // :172
+    int kf = 0, f = 0;  // first pair of the current node on each side (the map iterators KFit, Fit)
+    while (kf < fv_n_kf && f < fv_n_f) {  // :180
+        const uint32_t node_kf = fv_node_kf[kf], node_f = fv_node_f[f];
+        if (node_kf == node_f) {  // :182
+            int kf_end = kf, f_end = f;
+            while (kf_end < fv_n_kf && fv_node_kf[kf_end] == node_kf) kf_end++;
+            while (f_end < fv_n_f && fv_node_f[f_end] == node_f) f_end++;
+            for (int iKF = kf; iKF < kf_end; iKF++) {  // :187
+                const unsigned realIdxKF = fv_idx_kf[iKF];
+                if (!valid_kf[realIdxKF]) continue;  // :193-197
+                const uint8_t* dKF = desc_kf + (size_t)realIdxKF * 32;
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;  // :201-203
+                for (int iF = f; iF < f_end; iF++) {
+                    const unsigned realIdxF = fv_idx_f[iF];
+                    if (match[realIdxF] >= 0) continue;  // :209-210
+                    const int dist = orc_descriptor_distance(dKF, desc_f + (size_t)realIdxF * 32);
+                    if (dist < bestDist1) {  // :216-225
+                        bestDist2 = bestDist1;
+                        bestDist1 = dist;
+                        bestIdxF = (int)realIdxF;
+                    } else if (dist < bestDist2) {
+                        bestDist2 = dist;
+                    }
+                }
+                if (bestDist1 <= TH_LOW) {  // :228
+                    if ((float)bestDist1 < nn_ratio * (float)bestDist2) {  // :230
+                        match[bestIdxF] = (int)realIdxKF;
+                        if (check_orientation) {  // :236-248
+                            float rot = angle_kf[realIdxKF] - angle_f[bestIdxF];
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)std::round(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back(bestIdxF);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            kf = kf_end;  // :253-254
+            f = f_end;
+        } else if (node_kf < node_f) {  // :256-259: lower_bound(Fit->first)
+            while (kf < fv_n_kf && fv_node_kf[kf] < node_f) kf++;
+        } else {  // :260-263
+            while (f < fv_n_f && fv_node_f[f] < node_kf) f++;
+        }
+    }
+    if (check_orientation) {  // :267-288
+        int ind1 = -1, ind2 = -1, ind3 = -1, size[30];
+        for (int i = 0; i < HISTO_LENGTH; i++) size[i] = (int)rotHist[i].size();
+        three_maxima(size, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (size_t j = 0; j < rotHist[i].size(); j++) {
+                    match[rotHist[i][j]] = -1;
+                    nmatches--;
+                }
+    }
+    return nmatches;
+}

@@ -265,6 +265,13 @@ int orc_search_local_map(const float* kps_xy, const int32_t* octave, const uint8
                          const float* scale_factors, float min_x, float min_y, float inv_w, float inv_h, float th,
                          float nn_ratio, const orc_local_query* q, int nq, int32_t* match, int32_t* query_match);
 
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (reference src/ORBmatcher.cc:159-290).
+ * FeatureVectors as (node, feature index) pairs sorted by node, then index. */
+int orc_search_by_bow(const uint32_t* fv_node_kf, const uint32_t* fv_idx_kf, int fv_n_kf, const uint8_t* desc_kf,
+                      const float* angle_kf, const uint8_t* valid_kf, const uint32_t* fv_node_f, const uint32_t* fv_idx_f,
+                      int fv_n_f, const uint8_t* desc_f, const float* angle_f, int n_f, float nn_ratio,
+                      int check_orientation, int32_t* match);
+
 #ifdef __cplusplus
 }
 #endif

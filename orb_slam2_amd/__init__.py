@@ -53,7 +53,7 @@ EXPORTS = [
     "orbx_undistort_grid_batch_device",
     "orbx_voc_create", "orbx_voc_load_text", "orbx_voc_destroy", "orbx_voc_info", "orbx_voc_node", "orbx_bow_transform_batch_device", "orbx_search_window_batch_device",
     "orbx_search_by_projection_batch_device", "orbx_set_debug_flag",
-    "orbx_stereo_match_batch_device_noalloc", "orbx_search_local_map_batch_device",
+    "orbx_stereo_match_batch_device_noalloc", "orbx_search_local_map_batch_device", "orbx_search_by_bow_batch_device",
 ]
 
 _lib = None
@@ -96,6 +96,7 @@ def load_library():
     L.orbx_search_by_projection_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32]
     L.orbx_search_local_map_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, vp, i32, vp,
                                                      vp, vp, vp, i32]
+    L.orbx_search_by_bow_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, f32, i32, vp, vp, i32]
     L.orbx_gray_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, i32, i32, vp, i32, C.c_size_t, i32]
     L.orbx_remap_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, vp, vp, i32, vp, i32, i32, i32,
                                           C.c_size_t, i32]
@@ -369,6 +370,18 @@ class ORBextractor:
             C.c_void_p(d_u_right or None), C.c_void_p(d_taken or None), min_x, min_y, inv_w, inv_h, th, nn_ratio,
             C.c_void_p(d_queries), q_cap, C.c_void_p(d_nq), C.c_void_p(d_match), C.c_void_p(d_query_match),
             C.c_void_p(d_nmatches), int(sync)), self._ctx)
+
+    def search_by_bow_batch_device(self, n, d_fv_node_kf, d_fv_idx_kf, d_fv_n_kf, d_desc_kf, d_kps_kf, d_valid_kf, kp_cap_kf,
+                                   d_fv_node_f, d_fv_idx_f, d_fv_n_f, d_desc_f, d_kps_f, kp_cap_f, nn_ratio, check_orientation,
+                                   d_match, d_nmatches, sync=True):
+        """ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) (src/ORBmatcher.cc:159-290) for a batch of (keyframe, frame)
+        pairs on the FeatureVectors bow_transform_batch_device leaves; raw device addresses; see
+        orbx_search_by_bow_batch_device."""
+        _check(self._L.orbx_search_by_bow_batch_device(
+            self._ctx, n, C.c_void_p(d_fv_node_kf), C.c_void_p(d_fv_idx_kf), C.c_void_p(d_fv_n_kf), C.c_void_p(d_desc_kf),
+            C.c_void_p(d_kps_kf), C.c_void_p(d_valid_kf), kp_cap_kf, C.c_void_p(d_fv_node_f), C.c_void_p(d_fv_idx_f),
+            C.c_void_p(d_fv_n_f), C.c_void_p(d_desc_f), C.c_void_p(d_kps_f), kp_cap_f, nn_ratio, int(check_orientation),
+            C.c_void_p(d_match), C.c_void_p(d_nmatches), int(sync)), self._ctx)
 
     # ---- the stage after the extractor: Frame::ComputeStereoMatches (src/Frame.cc:485-659) ----
     def stereo_match(self, right, mb, mbf, img_left=0, img_right=0):

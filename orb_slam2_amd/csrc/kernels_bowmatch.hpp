@@ -1,0 +1,212 @@
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (reference src/ORBmatcher.cc:159-290):
+// the features of a keyframe and of a frame that fall into the same vocabulary node are matched, node by
+// node (called from Tracking::TrackReferenceKeyFrame, src/Tracking.cc:894, and Tracking::Relocalization, :1563).
+#ifndef ORBX_KERNELS_BOWMATCH_HPP
+#define ORBX_KERNELS_BOWMATCH_HPP
+
+#include "kernels_bow.hpp"
+
+namespace orbx {
+
+constexpr int kBowMatchThreads = 1024;
+constexpr int kThLow = 50;  // ORBmatcher.cc:38
+
+struct BowMatchDev {
+    // the keyframe side of pair f: FeatureVector pairs [f*cap_kf .. + fv_n_kf[f]), descriptors, keypoints
+    // (for the angle), and per feature whether it holds a map point that is not bad (:193-197)
+    const uint32_t *fv_node_kf, *fv_idx_kf;
+    const int32_t* fv_n_kf;
+    const uint8_t* desc_kf;
+    const orbx_kp* kps_kf;
+    const uint8_t* valid_kf;
+    int cap_kf;
+    // the frame side
+    const uint32_t *fv_node_f, *fv_idx_f;
+    const int32_t* fv_n_f;
+    const uint8_t* desc_f;
+    const orbx_kp* kps_f;
+    int cap_f;
+    float nn_ratio;
+    int check_orientation;
+    int32_t* match;      // [n][cap_f]: keyframe feature whose map point the frame feature ends with, -1: none
+    int32_t* n_matches;  // [n]
+    int taken_words;     // 32-bit words of "already matched" flags per lane: ceil(ceil(cap_f / 64) / 32)
+};
+
+// Two sorted pairs of keys (k1 <= k2, o1 <= o2) -> the two smallest of the four.
+__device__ __forceinline__ void bow_top2_merge(uint32_t& k1, uint32_t& k2, uint32_t o1, uint32_t o2) {
+    const uint32_t lo = min(k1, o1), hi = max(k1, o1);
+    k2 = min(hi, min(k2, o2));
+    k1 = lo;
+}
+
+// First index in [from, n) whose node differs from `node` (n if none), found by the wave 64 entries at a time.
+__device__ __forceinline__ int bow_run_end(const uint32_t* nodes, int from, int n, uint32_t node) {
+    const int lane = threadIdx.x & 63;
+    for (int e = from;; e += 64) {
+        const int c = e + lane;
+        const bool differs = c >= n || nodes[c] != node;
+        const uint64_t m = __ballot(differs);
+        if (m) return e + __builtin_ctzll(m);
+    }
+}
+
+// One workgroup per (keyframe, frame) pair.  Nodes are independent of each other (a feature belongs to one
+// node), so the waves share the keyframe's runs of equal node id; inside a run the reference's loop over the
+// keyframe's features is kept as it is, because a frame feature taken by one of them is skipped by the next
+// (:209-210).  For one keyframe feature the 64 lanes scan the frame's features of the node (the first 64 stay
+// in registers for the whole run), each keeps its two smallest (distance, list position) keys, a butterfly
+// merge leaves the wave's two smallest: the reference's bestDist1 / bestIdxF / bestDist2 (:216-225 takes the
+// first of equal distances, and bestDist2 ends as the second smallest distance of the list).  The "taken"
+// flags of the run's candidates are one bit per (lane, chunk of 64) in LDS.  A match is written as keyframe
+// feature | rotation bin << 24; after all runs the 30-bin histogram decides which bins stay (:267-288,
+// ComputeThreeMaxima :1638-1679) and a last pass over the frame's features strips or clears the entries.
+// grid = pairs, block = 1024, dynamic LDS = 16 waves * taken_words * 64 * 4 bytes.
+__global__ __launch_bounds__(kBowMatchThreads) void k_search_bow(BowMatchDev D) {
+    extern __shared__ uint32_t s_taken[];
+    __shared__ int s_nm, s_hist[kHistoLength], s_keep[3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, f = blockIdx.x;
+    const int nkf = D.fv_n_kf[f], nf = D.fv_n_f[f];
+    const uint32_t* nodes_kf = D.fv_node_kf + (size_t)f * D.cap_kf;
+    const uint32_t* idx_kf = D.fv_idx_kf + (size_t)f * D.cap_kf;
+    const uint8_t* desc_kf = D.desc_kf + (size_t)f * D.cap_kf * 32;
+    const orbx_kp* kps_kf = D.kps_kf + (size_t)f * D.cap_kf;
+    const uint8_t* valid_kf = D.valid_kf + (size_t)f * D.cap_kf;
+    const uint32_t* nodes_f = D.fv_node_f + (size_t)f * D.cap_f;
+    const uint32_t* idx_f = D.fv_idx_f + (size_t)f * D.cap_f;
+    const uint8_t* desc_f = D.desc_f + (size_t)f * D.cap_f * 32;
+    const orbx_kp* kps_f = D.kps_f + (size_t)f * D.cap_f;
+    int32_t* match = D.match + (size_t)f * D.cap_f;
+
+    for (int i = tid; i < D.cap_f; i += kBowMatchThreads) match[i] = -1;  // :163
+    if (tid < kHistoLength) s_hist[tid] = 0;
+    if (tid == 0) s_nm = 0;
+    __syncthreads();
+
+    uint32_t* my_taken = s_taken + (size_t)wave * D.taken_words * 64;
+    constexpr uint32_t kNone = (256u << 16) | 0xFFFFu;  // no candidate: distance 256 (:201-203)
+    // the wave's slice of the keyframe's pairs; it works on the runs whose first pair lies in the slice
+    const int per = ((nkf + kBowMatchThreads - 1) / kBowMatchThreads) * 64;
+    const int beg = wave * per, end = min(beg + per, nkf);
+    for (int i0 = beg; i0 < end; i0 += 64) {
+        const int i = i0 + lane;
+        const uint32_t node_i = i < end ? nodes_kf[i] : 0u;
+        const bool head = i < end && (i == 0 || nodes_kf[i - 1] != node_i);
+        uint64_t heads = __ballot(head);
+        while (heads) {
+            const int hl = __builtin_ctzll(heads);
+            heads &= heads - 1;
+            const int h = i0 + hl;
+            const uint32_t node = (uint32_t)__builtin_amdgcn_readlane((int)node_i, hl);
+            const int e = bow_run_end(nodes_kf, h + 1, nkf, node);
+            // the frame's pairs of the same node: lower bound, then the end of the run (:182, :256-263)
+            int lo = 0, hi = nf;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (nodes_f[mid] < node) lo = mid + 1; else hi = mid;
+            }
+            if (lo >= nf || nodes_f[lo] != node) continue;
+            const int fe = bow_run_end(nodes_f, lo + 1, nf, node);
+            const int chunks = (fe - lo + 63) >> 6;
+            for (int w = 0; w < (chunks + 31) >> 5; ++w) my_taken[w * 64 + lane] = 0u;
+            // the first 64 candidates stay in registers for the whole run
+            const bool has0 = lo + lane < fe;
+            uint4 c0a = make_uint4(0, 0, 0, 0), c0b = make_uint4(0, 0, 0, 0);
+            if (has0) {
+                const uint4* p = reinterpret_cast<const uint4*>(desc_f + (size_t)idx_f[lo + lane] * 32);
+                c0a = p[0];
+                c0b = p[1];
+            }
+            for (int k = h; k < e; ++k) {  // :187
+                const uint32_t kf_idx = idx_kf[k];
+                if (!valid_kf[kf_idx]) continue;  // :193-197
+                const uint4* pk = reinterpret_cast<const uint4*>(desc_kf + (size_t)kf_idx * 32);
+                const uint4 ka = pk[0], kb = pk[1];
+                uint32_t k1 = kNone, k2 = kNone;
+                for (int j = 0; j < chunks; ++j) {
+                    const int c = lo + lane + 64 * j;
+                    const uint32_t tw = my_taken[(j >> 5) * 64 + lane];
+                    if (c < fe && !((tw >> (j & 31)) & 1u)) {  // :209-210
+                        uint4 a = c0a, b = c0b;
+                        if (j > 0) {
+                            const uint4* p = reinterpret_cast<const uint4*>(desc_f + (size_t)idx_f[c] * 32);
+                            a = p[0];
+                            b = p[1];
+                        }
+                        const int dist = __popc(a.x ^ ka.x) + __popc(a.y ^ ka.y) + __popc(a.z ^ ka.z) + __popc(a.w ^ ka.w) +
+                                         __popc(b.x ^ kb.x) + __popc(b.y ^ kb.y) + __popc(b.z ^ kb.z) + __popc(b.w ^ kb.w);
+                        if (dist < 256) {  // a distance of 256 beats neither 256 (:216, :222)
+                            const uint32_t key = ((uint32_t)dist << 16) | (uint32_t)(c - lo);
+                            if (key < k1) {
+                                k2 = k1;
+                                k1 = key;
+                            } else if (key < k2) {
+                                k2 = key;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t o1 = (uint32_t)__shfl_xor((int)k1, off), o2 = (uint32_t)__shfl_xor((int)k2, off);
+                    bow_top2_merge(k1, k2, o1, o2);
+                }
+                const int best1 = (int)(k1 >> 16), best2 = (int)(k2 >> 16);
+                if (best1 <= kThLow && (float)best1 < __fmul_rn(D.nn_ratio, (float)best2)) {  // :228-230
+                    const int pos = (int)(k1 & 0xFFFFu);
+                    const uint32_t idxF = idx_f[lo + pos];
+                    if (lane == (pos & 63)) my_taken[((pos >> 6) >> 5) * 64 + lane] |= 1u << ((pos >> 6) & 31);
+                    const int bin = D.check_orientation ? proj_rot_bin(kps_kf[kf_idx].angle, kps_f[idxF].angle) : 0;  // :236-248
+                    if (lane == 0) {
+                        match[idxF] = (int32_t)(kf_idx | ((uint32_t)bin << 24));
+                        atomicAdd(&s_nm, 1);
+                        if (D.check_orientation) atomicAdd(&s_hist[bin], 1);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (D.check_orientation && tid == 0) {  // ComputeThreeMaxima (:1638-1679)
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < kHistoLength; ++i) {
+            const int s = s_hist[i];
+            if (s > max1) {
+                max3 = max2; max2 = max1; max1 = s;
+                ind3 = ind2; ind2 = ind1; ind1 = i;
+            } else if (s > max2) {
+                max3 = max2; max2 = s;
+                ind3 = ind2; ind2 = i;
+            } else if (s > max3) {
+                max3 = s;
+                ind3 = i;
+            }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
+            ind2 = -1;
+            ind3 = -1;
+        } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
+            ind3 = -1;
+        }
+        s_keep[0] = ind1;
+        s_keep[1] = ind2;
+        s_keep[2] = ind3;
+    }
+    __syncthreads();
+    for (int i = tid; i < D.cap_f; i += kBowMatchThreads) {
+        const int m = __hip_atomic_load(&match[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (m < 0) continue;
+        const int bin = m >> 24;
+        if (D.check_orientation && bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) {  // :276-286
+            match[i] = -1;
+            atomicSub(&s_nm, 1);
+        } else {
+            match[i] = m & 0xFFFFFF;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) D.n_matches[f] = s_nm;
+}
+
+}  // namespace orbx
+#endif

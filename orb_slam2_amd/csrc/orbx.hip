@@ -17,6 +17,7 @@
 #include "kernels_octree.hpp"
 #include "kernels_post.hpp"
 #include "kernels_bow.hpp"
+#include "kernels_bowmatch.hpp"
 #include "kernels_pyramid.hpp"
 #include "kernels_staging.hpp"
 #include "kernels_stereo.hpp"
@@ -1554,6 +1555,45 @@ extern "C" int orbx_search_local_map_batch_device(orbx_ctx* c, int n, const orbx
     const size_t lds = ((size_t)2 * kp_cap + (size_t)2 * q_cap) * 4;
     D.use_lds = lds <= 64 * 1024 ? 1 : 0;
     hipLaunchKernelGGL(k_search_local, dim3(n), dim3(kProjThreads), D.use_lds ? lds : 0, c->stream, D);
+    HIP_TRY(c, hipGetLastError());
+    if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_search_by_bow_batch_device(orbx_ctx* c, int n, const uint32_t* d_fv_node_kf, const uint32_t* d_fv_idx_kf,
+                                               const int32_t* d_fv_n_kf, const uint8_t* d_desc_kf, const orbx_kp* d_kps_kf,
+                                               const uint8_t* d_valid_kf, int kp_cap_kf, const uint32_t* d_fv_node_f,
+                                               const uint32_t* d_fv_idx_f, const int32_t* d_fv_n_f, const uint8_t* d_desc_f,
+                                               const orbx_kp* d_kps_f, int kp_cap_f, float nn_ratio, int check_orientation,
+                                               int32_t* d_match, int32_t* d_nmatches, int sync) {
+    if (!c || !d_fv_node_kf || !d_fv_idx_kf || !d_fv_n_kf || !d_desc_kf || !d_kps_kf || !d_valid_kf || !d_fv_node_f ||
+        !d_fv_idx_f || !d_fv_n_f || !d_desc_f || !d_kps_f || !d_match || !d_nmatches || n < 1 || kp_cap_kf < 1 ||
+        kp_cap_f < 1 || !(nn_ratio > 0.0f))
+        return ORBX_E_INVALID;
+    if (kp_cap_kf > 16384 || kp_cap_f > 16384) return ORBX_E_CAPACITY;  // as the bag-of-words transform; 24 bits of a match entry hold the feature
+    HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    { int rc_ = join(c); if (rc_) return rc_; }
+    BowMatchDev D;
+    D.fv_node_kf = d_fv_node_kf;
+    D.fv_idx_kf = d_fv_idx_kf;
+    D.fv_n_kf = d_fv_n_kf;
+    D.desc_kf = d_desc_kf;
+    D.kps_kf = d_kps_kf;
+    D.valid_kf = d_valid_kf;
+    D.cap_kf = kp_cap_kf;
+    D.fv_node_f = d_fv_node_f;
+    D.fv_idx_f = d_fv_idx_f;
+    D.fv_n_f = d_fv_n_f;
+    D.desc_f = d_desc_f;
+    D.kps_f = d_kps_f;
+    D.cap_f = kp_cap_f;
+    D.nn_ratio = nn_ratio;
+    D.check_orientation = check_orientation ? 1 : 0;
+    D.match = d_match;
+    D.n_matches = d_nmatches;
+    D.taken_words = ((kp_cap_f + 63) / 64 + 31) / 32;
+    const size_t lds = (size_t)(kBowMatchThreads / 64) * D.taken_words * 64 * 4;
+    hipLaunchKernelGGL(k_search_bow, dim3(n), dim3(kBowMatchThreads), lds, c->stream, D);
     HIP_TRY(c, hipGetLastError());
     if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     return ORBX_OK;

@@ -393,6 +393,23 @@ def search_local_map(xy, octave, desc, u_right, taken0, cell_start, cell_idx, sc
     return n, match[:n_kp], qmatch[:len(q)]
 
 
+def search_by_bow(fv_node_kf, fv_idx_kf, desc_kf, angle_kf, valid_kf, fv_node_f, fv_idx_f, desc_f, angle_f, nn_ratio,
+                  check_orientation):
+    """ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) (reference src/ORBmatcher.cc:159-290) on FeatureVectors
+    given as (node, feature index) pairs; returns (nmatches, keyframe feature per frame feature)."""
+    L = lib()
+    L.orc_search_by_bow.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    a = [np.ascontiguousarray(x, t) for x, t in ((fv_node_kf, np.uint32), (fv_idx_kf, np.uint32), (desc_kf, np.uint8),
+                                                  (angle_kf, np.float32), (valid_kf, np.uint8), (fv_node_f, np.uint32),
+                                                  (fv_idx_f, np.uint32), (desc_f, np.uint8), (angle_f, np.float32))]
+    n_f = len(a[8])
+    match = np.full(max(n_f, 1), -1, np.int32)
+    n = L.orc_search_by_bow(_ptr(a[0]), _ptr(a[1]), len(a[0]), _ptr(a[2]), _ptr(a[3]), _ptr(a[4]), _ptr(a[5]), _ptr(a[6]),
+                            len(a[5]), _ptr(a[7]), _ptr(a[8]), n_f, nn_ratio, int(check_orientation), _ptr(match))
+    return n, match[:n_f]
+
+
 class Vocabulary:
     """A DBoW2 vocabulary tree in the oracle (TemplatedVocabulary, reference
     Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h).  Arrays are per node, entry 0 = root."""
