@@ -320,7 +320,7 @@ def rate_entry(oa, cfg, n, sec_per_step, counts, note):
 
 
 def extras(torch, oa, device):
-    """The other BASELINE configurations on this GPU, each with its own algorithmic-byte fraction."""
+    """The other configurations of the benchmark suite on this GPU, each with its own algorithmic-byte fraction."""
     out = {}
     # ---- C2: 640x480 / 1000 features: single-frame latency of the host-memory entry point, batched rate ----
     try:
