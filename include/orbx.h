@@ -330,6 +330,19 @@ int orbx_search_by_bow_batch_device(orbx_ctx* ctx, int n, const uint32_t* d_fv_n
                                     const orbx_kp* d_kps_f, int kp_cap_f, float nn_ratio, int check_orientation,
                                     int32_t* d_match, int32_t* d_nmatches, int sync);
 
+/* Replaces ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (reference
+ * src/ORBmatcher.cc:551-684; called from LoopClosing::ComputeSim3, src/LoopClosing.cc:268): the same node-by-node
+ * matching between two keyframes.  Features of the second keyframe need a good map point too (d_valid_2), the
+ * best distance must be below TH_LOW (< 50, not <=), and the result is indexed by the first keyframe's
+ * features: d_match12[f*kp_cap_1 + i] = the feature of the second keyframe whose map point vpMatches12[i]
+ * becomes (-1: NULL).  Everything else as orbx_search_by_bow_batch_device. */
+int orbx_search_by_bow_keyframes_batch_device(orbx_ctx* ctx, int n, const uint32_t* d_fv_node_1, const uint32_t* d_fv_idx_1,
+                                              const int32_t* d_fv_n_1, const uint8_t* d_desc_1, const orbx_kp* d_kps_1,
+                                              const uint8_t* d_valid_1, int kp_cap_1, const uint32_t* d_fv_node_2,
+                                              const uint32_t* d_fv_idx_2, const int32_t* d_fv_n_2, const uint8_t* d_desc_2,
+                                              const orbx_kp* d_kps_2, const uint8_t* d_valid_2, int kp_cap_2, float nn_ratio,
+                                              int check_orientation, int32_t* d_match12, int32_t* d_nmatches, int sync);
+
 /* ---- the stage after the extractor: stereo association ---------------------------------
  * Replaces Frame::ComputeStereoMatches (reference src/Frame.cc:485-659, descriptor distance
  * src/ORBmatcher.cc:1684-1700): for every left keypoint the best right keypoint in its row

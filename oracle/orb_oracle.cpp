@@ -1582,3 +1582,79 @@ extern "C" int orc_search_by_bow(const uint32_t* fv_node_kf, const uint32_t* fv_
     }
     return nmatches;
 }
+
+// ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) (reference src/ORBmatcher.cc:551-684), the
+// matcher of the loop closer: as above between two keyframes.  valid_1 / valid_2: the feature holds a map point
+// that is not bad; match12[i] = the feature of the second keyframe whose map point vpMatches12[i] becomes
+// (-1: NULL); returns nmatches.
+extern "C" int orc_search_by_bow_keyframes(const uint32_t* fv_node_1, const uint32_t* fv_idx_1, int fv_n_1,
+                                           const uint8_t* desc_1, const float* angle_1, const uint8_t* valid_1, int n_1,
+                                           const uint32_t* fv_node_2, const uint32_t* fv_idx_2, int fv_n_2,
+                                           const uint8_t* desc_2, const float* angle_2, const uint8_t* valid_2, int n_2,
+                                           float nn_ratio, int check_orientation, int32_t* match12) {
+    const int HISTO_LENGTH = 30, TH_LOW = 50;
+    for (int i = 0; i < n_1; i++) match12[i] = -1;  // :563
+    std::vector<uint8_t> vbMatched2((size_t)std::max(n_2, 1), 0);  // :564
+    std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+    const float factor = 1.0f / HISTO_LENGTH;  // :570
+    int nmatches = 0;
+    int a = 0, b = 0;  // first pair of the current node on each side (f1it, f2it)
+    while (a < fv_n_1 && b < fv_n_2) {  // :579
+        const uint32_t node_1 = fv_node_1[a], node_2 = fv_node_2[b];
+        if (node_1 == node_2) {  // :581
+            int a_end = a, b_end = b;
+            while (a_end < fv_n_1 && fv_node_1[a_end] == node_1) a_end++;
+            while (b_end < fv_n_2 && fv_node_2[b_end] == node_2) b_end++;
+            for (int i1 = a; i1 < a_end; i1++) {  // :583
+                const unsigned idx1 = fv_idx_1[i1];
+                if (!valid_1[idx1]) continue;  // :587-591
+                const uint8_t* d1 = desc_1 + (size_t)idx1 * 32;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;  // :595-597
+                for (int i2 = b; i2 < b_end; i2++) {
+                    const unsigned idx2 = fv_idx_2[i2];
+                    if (vbMatched2[idx2] || !valid_2[idx2]) continue;  // :603-609
+                    const int dist = orc_descriptor_distance(d1, desc_2 + (size_t)idx2 * 32);
+                    if (dist < bestDist1) {  // :615-624
+                        bestDist2 = bestDist1;
+                        bestDist1 = dist;
+                        bestIdx2 = (int)idx2;
+                    } else if (dist < bestDist2) {
+                        bestDist2 = dist;
+                    }
+                }
+                if (bestDist1 < TH_LOW) {  // :627
+                    if ((float)bestDist1 < nn_ratio * (float)bestDist2) {  // :629
+                        match12[idx1] = bestIdx2;  // :631-632
+                        vbMatched2[bestIdx2] = 1;
+                        if (check_orientation) {  // :634-645
+                            float rot = angle_1[idx1] - angle_2[bestIdx2];
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)std::round(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back((int)idx1);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            a = a_end;  // :650-651
+            b = b_end;
+        } else if (node_1 < node_2) {  // :653-656
+            while (a < fv_n_1 && fv_node_1[a] < node_2) a++;
+        } else {  // :657-660
+            while (b < fv_n_2 && fv_node_2[b] < node_1) b++;
+        }
+    }
+    if (check_orientation) {  // :663-682
+        int ind1 = -1, ind2 = -1, ind3 = -1, size[30];
+        for (int i = 0; i < HISTO_LENGTH; i++) size[i] = (int)rotHist[i].size();
+        three_maxima(size, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (size_t j = 0; j < rotHist[i].size(); j++) {
+                    match12[rotHist[i][j]] = -1;
+                    nmatches--;
+                }
+    }
+    return nmatches;
+}

@@ -272,6 +272,12 @@ int orc_search_by_bow(const uint32_t* fv_node_kf, const uint32_t* fv_idx_kf, int
                       int fv_n_f, const uint8_t* desc_f, const float* angle_f, int n_f, float nn_ratio,
                       int check_orientation, int32_t* match);
 
+/* ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (reference src/ORBmatcher.cc:551-684). */
+int orc_search_by_bow_keyframes(const uint32_t* fv_node_1, const uint32_t* fv_idx_1, int fv_n_1, const uint8_t* desc_1,
+                                const float* angle_1, const uint8_t* valid_1, int n_1, const uint32_t* fv_node_2,
+                                const uint32_t* fv_idx_2, int fv_n_2, const uint8_t* desc_2, const float* angle_2,
+                                const uint8_t* valid_2, int n_2, float nn_ratio, int check_orientation, int32_t* match12);
+
 #ifdef __cplusplus
 }
 #endif

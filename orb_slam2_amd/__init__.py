@@ -54,6 +54,7 @@ EXPORTS = [
     "orbx_voc_create", "orbx_voc_load_text", "orbx_voc_destroy", "orbx_voc_info", "orbx_voc_node", "orbx_bow_transform_batch_device", "orbx_search_window_batch_device",
     "orbx_search_by_projection_batch_device", "orbx_set_debug_flag",
     "orbx_stereo_match_batch_device_noalloc", "orbx_search_local_map_batch_device", "orbx_search_by_bow_batch_device",
+    "orbx_search_by_bow_keyframes_batch_device",
 ]
 
 _lib = None
@@ -97,6 +98,8 @@ def load_library():
     L.orbx_search_local_map_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, vp, i32, vp,
                                                      vp, vp, vp, i32]
     L.orbx_search_by_bow_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, f32, i32, vp, vp, i32]
+    L.orbx_search_by_bow_keyframes_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, f32,
+                                                            i32, vp, vp, i32]
     L.orbx_gray_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, i32, i32, vp, i32, C.c_size_t, i32]
     L.orbx_remap_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, vp, vp, i32, vp, i32, i32, i32,
                                           C.c_size_t, i32]
@@ -382,6 +385,17 @@ class ORBextractor:
             C.c_void_p(d_kps_kf), C.c_void_p(d_valid_kf), kp_cap_kf, C.c_void_p(d_fv_node_f), C.c_void_p(d_fv_idx_f),
             C.c_void_p(d_fv_n_f), C.c_void_p(d_desc_f), C.c_void_p(d_kps_f), kp_cap_f, nn_ratio, int(check_orientation),
             C.c_void_p(d_match), C.c_void_p(d_nmatches), int(sync)), self._ctx)
+
+    def search_by_bow_keyframes_batch_device(self, n, d_fv_node_1, d_fv_idx_1, d_fv_n_1, d_desc_1, d_kps_1, d_valid_1, kp_cap_1,
+                                             d_fv_node_2, d_fv_idx_2, d_fv_n_2, d_desc_2, d_kps_2, d_valid_2, kp_cap_2, nn_ratio,
+                                             check_orientation, d_match12, d_nmatches, sync=True):
+        """ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (src/ORBmatcher.cc:551-684) for a batch of keyframe pairs;
+        see orbx_search_by_bow_keyframes_batch_device."""
+        _check(self._L.orbx_search_by_bow_keyframes_batch_device(
+            self._ctx, n, C.c_void_p(d_fv_node_1), C.c_void_p(d_fv_idx_1), C.c_void_p(d_fv_n_1), C.c_void_p(d_desc_1),
+            C.c_void_p(d_kps_1), C.c_void_p(d_valid_1), kp_cap_1, C.c_void_p(d_fv_node_2), C.c_void_p(d_fv_idx_2),
+            C.c_void_p(d_fv_n_2), C.c_void_p(d_desc_2), C.c_void_p(d_kps_2), C.c_void_p(d_valid_2), kp_cap_2, nn_ratio,
+            int(check_orientation), C.c_void_p(d_match12), C.c_void_p(d_nmatches), int(sync)), self._ctx)
 
     # ---- the stage after the extractor: Frame::ComputeStereoMatches (src/Frame.cc:485-659) ----
     def stereo_match(self, right, mb, mbf, img_left=0, img_right=0):

@@ -1,6 +1,8 @@
 // ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (reference src/ORBmatcher.cc:159-290):
 // the features of a keyframe and of a frame that fall into the same vocabulary node are matched, node by
-// node (called from Tracking::TrackReferenceKeyFrame, src/Tracking.cc:894, and Tracking::Relocalization, :1563).
+// node (called from Tracking::TrackReferenceKeyFrame, src/Tracking.cc:894, and Tracking::Relocalization, :1563),
+// and ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) (:551-684, called from
+// LoopClosing::ComputeSim3, src/LoopClosing.cc:268), the same loop between two keyframes.
 #ifndef ORBX_KERNELS_BOWMATCH_HPP
 #define ORBX_KERNELS_BOWMATCH_HPP
 
@@ -28,7 +30,13 @@ struct BowMatchDev {
     int cap_f;
     float nn_ratio;
     int check_orientation;
-    int32_t* match;      // [n][cap_f]: keyframe feature whose map point the frame feature ends with, -1: none
+    // Two keyframes (:551-684) instead of keyframe and frame: the second side's features need a good map point
+    // too (valid_f, :603-609), the best distance must be BELOW TH_LOW (:627), and the result is indexed by the
+    // first keyframe's features (vpMatches12, :631).
+    int two_keyframes;
+    const uint8_t* valid_f;
+    int32_t* match;      // [n][cap_f]: keyframe feature whose map point the frame feature ends with, -1: none;
+                         // two keyframes: [n][cap_kf]: the second keyframe's feature per feature of the first
     int32_t* n_matches;  // [n]
     int taken_words;     // 32-bit words of "already matched" flags per lane: ceil(ceil(cap_f / 64) / 32)
 };
@@ -76,9 +84,12 @@ __global__ __launch_bounds__(kBowMatchThreads) void k_search_bow(BowMatchDev D) 
     const uint32_t* idx_f = D.fv_idx_f + (size_t)f * D.cap_f;
     const uint8_t* desc_f = D.desc_f + (size_t)f * D.cap_f * 32;
     const orbx_kp* kps_f = D.kps_f + (size_t)f * D.cap_f;
-    int32_t* match = D.match + (size_t)f * D.cap_f;
+    const uint8_t* valid_f = D.two_keyframes ? D.valid_f + (size_t)f * D.cap_f : nullptr;
+    const int cap_out = D.two_keyframes ? D.cap_kf : D.cap_f;
+    int32_t* match = D.match + (size_t)f * cap_out;
+    const int th_low = D.two_keyframes ? kThLow - 1 : kThLow;  // :228 "<= TH_LOW", :627 "< TH_LOW"
 
-    for (int i = tid; i < D.cap_f; i += kBowMatchThreads) match[i] = -1;  // :163
+    for (int i = tid; i < cap_out; i += kBowMatchThreads) match[i] = -1;  // :163, :563
     if (tid < kHistoLength) s_hist[tid] = 0;
     if (tid == 0) s_nm = 0;
     __syncthreads();
@@ -109,6 +120,11 @@ __global__ __launch_bounds__(kBowMatchThreads) void k_search_bow(BowMatchDev D) 
             const int fe = bow_run_end(nodes_f, lo + 1, nf, node);
             const int chunks = (fe - lo + 63) >> 6;
             for (int w = 0; w < (chunks + 31) >> 5; ++w) my_taken[w * 64 + lane] = 0u;
+            if (valid_f)  // a feature of the second keyframe without a good map point is never a candidate (:603-609)
+                for (int j = 0; j < chunks; ++j) {
+                    const int c = lo + lane + 64 * j;
+                    if (c < fe && !valid_f[idx_f[c]]) my_taken[(j >> 5) * 64 + lane] |= 1u << (j & 31);
+                }
             // the first 64 candidates stay in registers for the whole run
             const bool has0 = lo + lane < fe;
             uint4 c0a = make_uint4(0, 0, 0, 0), c0b = make_uint4(0, 0, 0, 0);
@@ -152,13 +168,16 @@ __global__ __launch_bounds__(kBowMatchThreads) void k_search_bow(BowMatchDev D) 
                     bow_top2_merge(k1, k2, o1, o2);
                 }
                 const int best1 = (int)(k1 >> 16), best2 = (int)(k2 >> 16);
-                if (best1 <= kThLow && (float)best1 < __fmul_rn(D.nn_ratio, (float)best2)) {  // :228-230
+                if (best1 <= th_low && (float)best1 < __fmul_rn(D.nn_ratio, (float)best2)) {  // :228-230
                     const int pos = (int)(k1 & 0xFFFFu);
                     const uint32_t idxF = idx_f[lo + pos];
                     if (lane == (pos & 63)) my_taken[((pos >> 6) >> 5) * 64 + lane] |= 1u << ((pos >> 6) & 31);
                     const int bin = D.check_orientation ? proj_rot_bin(kps_kf[kf_idx].angle, kps_f[idxF].angle) : 0;  // :236-248
                     if (lane == 0) {
-                        match[idxF] = (int32_t)(kf_idx | ((uint32_t)bin << 24));
+                        if (D.two_keyframes)
+                            match[kf_idx] = (int32_t)(idxF | ((uint32_t)bin << 24));  // :631
+                        else
+                            match[idxF] = (int32_t)(kf_idx | ((uint32_t)bin << 24));  // :232
                         atomicAdd(&s_nm, 1);
                         if (D.check_orientation) atomicAdd(&s_hist[bin], 1);
                     }
@@ -193,7 +212,7 @@ __global__ __launch_bounds__(kBowMatchThreads) void k_search_bow(BowMatchDev D) 
         s_keep[2] = ind3;
     }
     __syncthreads();
-    for (int i = tid; i < D.cap_f; i += kBowMatchThreads) {
+    for (int i = tid; i < cap_out; i += kBowMatchThreads) {
         const int m = __hip_atomic_load(&match[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (m < 0) continue;
         const int bin = m >> 24;

@@ -1560,12 +1560,13 @@ extern "C" int orbx_search_local_map_batch_device(orbx_ctx* c, int n, const orbx
     return ORBX_OK;
 }
 
-extern "C" int orbx_search_by_bow_batch_device(orbx_ctx* c, int n, const uint32_t* d_fv_node_kf, const uint32_t* d_fv_idx_kf,
-                                               const int32_t* d_fv_n_kf, const uint8_t* d_desc_kf, const orbx_kp* d_kps_kf,
-                                               const uint8_t* d_valid_kf, int kp_cap_kf, const uint32_t* d_fv_node_f,
-                                               const uint32_t* d_fv_idx_f, const int32_t* d_fv_n_f, const uint8_t* d_desc_f,
-                                               const orbx_kp* d_kps_f, int kp_cap_f, float nn_ratio, int check_orientation,
-                                               int32_t* d_match, int32_t* d_nmatches, int sync) {
+namespace {
+// Both SearchByBoW overloads; d_valid_f != null selects the one between two keyframes.
+int search_by_bow(orbx_ctx* c, int n, const uint32_t* d_fv_node_kf, const uint32_t* d_fv_idx_kf, const int32_t* d_fv_n_kf,
+                  const uint8_t* d_desc_kf, const orbx_kp* d_kps_kf, const uint8_t* d_valid_kf, int kp_cap_kf,
+                  const uint32_t* d_fv_node_f, const uint32_t* d_fv_idx_f, const int32_t* d_fv_n_f, const uint8_t* d_desc_f,
+                  const orbx_kp* d_kps_f, const uint8_t* d_valid_f, int kp_cap_f, float nn_ratio, int check_orientation,
+                  int32_t* d_match, int32_t* d_nmatches, int sync) {
     if (!c || !d_fv_node_kf || !d_fv_idx_kf || !d_fv_n_kf || !d_desc_kf || !d_kps_kf || !d_valid_kf || !d_fv_node_f ||
         !d_fv_idx_f || !d_fv_n_f || !d_desc_f || !d_kps_f || !d_match || !d_nmatches || n < 1 || kp_cap_kf < 1 ||
         kp_cap_f < 1 || !(nn_ratio > 0.0f))
@@ -1589,6 +1590,8 @@ extern "C" int orbx_search_by_bow_batch_device(orbx_ctx* c, int n, const uint32_
     D.cap_f = kp_cap_f;
     D.nn_ratio = nn_ratio;
     D.check_orientation = check_orientation ? 1 : 0;
+    D.two_keyframes = d_valid_f ? 1 : 0;
+    D.valid_f = d_valid_f;
     D.match = d_match;
     D.n_matches = d_nmatches;
     D.taken_words = ((kp_cap_f + 63) / 64 + 31) / 32;
@@ -1597,6 +1600,33 @@ extern "C" int orbx_search_by_bow_batch_device(orbx_ctx* c, int n, const uint32_
     HIP_TRY(c, hipGetLastError());
     if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     return ORBX_OK;
+}
+}  // namespace
+
+extern "C" int orbx_search_by_bow_batch_device(orbx_ctx* c, int n, const uint32_t* d_fv_node_kf, const uint32_t* d_fv_idx_kf,
+                                               const int32_t* d_fv_n_kf, const uint8_t* d_desc_kf, const orbx_kp* d_kps_kf,
+                                               const uint8_t* d_valid_kf, int kp_cap_kf, const uint32_t* d_fv_node_f,
+                                               const uint32_t* d_fv_idx_f, const int32_t* d_fv_n_f, const uint8_t* d_desc_f,
+                                               const orbx_kp* d_kps_f, int kp_cap_f, float nn_ratio, int check_orientation,
+                                               int32_t* d_match, int32_t* d_nmatches, int sync) {
+    return search_by_bow(c, n, d_fv_node_kf, d_fv_idx_kf, d_fv_n_kf, d_desc_kf, d_kps_kf, d_valid_kf, kp_cap_kf, d_fv_node_f,
+                         d_fv_idx_f, d_fv_n_f, d_desc_f, d_kps_f, nullptr, kp_cap_f, nn_ratio, check_orientation, d_match,
+                         d_nmatches, sync);
+}
+
+extern "C" int orbx_search_by_bow_keyframes_batch_device(orbx_ctx* c, int n, const uint32_t* d_fv_node_1,
+                                                         const uint32_t* d_fv_idx_1, const int32_t* d_fv_n_1,
+                                                         const uint8_t* d_desc_1, const orbx_kp* d_kps_1,
+                                                         const uint8_t* d_valid_1, int kp_cap_1, const uint32_t* d_fv_node_2,
+                                                         const uint32_t* d_fv_idx_2, const int32_t* d_fv_n_2,
+                                                         const uint8_t* d_desc_2, const orbx_kp* d_kps_2,
+                                                         const uint8_t* d_valid_2, int kp_cap_2, float nn_ratio,
+                                                         int check_orientation, int32_t* d_match12, int32_t* d_nmatches,
+                                                         int sync) {
+    if (!d_valid_2) return ORBX_E_INVALID;
+    return search_by_bow(c, n, d_fv_node_1, d_fv_idx_1, d_fv_n_1, d_desc_1, d_kps_1, d_valid_1, kp_cap_1, d_fv_node_2, d_fv_idx_2,
+                         d_fv_n_2, d_desc_2, d_kps_2, d_valid_2, kp_cap_2, nn_ratio, check_orientation, d_match12, d_nmatches,
+                         sync);
 }
 
 extern "C" int orbx_synchronize(orbx_ctx* c) {

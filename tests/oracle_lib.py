@@ -410,6 +410,26 @@ def search_by_bow(fv_node_kf, fv_idx_kf, desc_kf, angle_kf, valid_kf, fv_node_f,
     return n, match[:n_f]
 
 
+def search_by_bow_keyframes(fv_node_1, fv_idx_1, desc_1, angle_1, valid_1, fv_node_2, fv_idx_2, desc_2, angle_2, valid_2,
+                            nn_ratio, check_orientation):
+    """ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (reference src/ORBmatcher.cc:551-684); returns (nmatches,
+    feature of the second keyframe per feature of the first)."""
+    L = lib()
+    L.orc_search_by_bow_keyframes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_float, C.c_int, C.c_void_p]
+    a = [np.ascontiguousarray(x, t) for x, t in ((fv_node_1, np.uint32), (fv_idx_1, np.uint32), (desc_1, np.uint8),
+                                                  (angle_1, np.float32), (valid_1, np.uint8), (fv_node_2, np.uint32),
+                                                  (fv_idx_2, np.uint32), (desc_2, np.uint8), (angle_2, np.float32),
+                                                  (valid_2, np.uint8))]
+    n_1, n_2 = len(a[3]), len(a[8])
+    match = np.full(max(n_1, 1), -1, np.int32)
+    n = L.orc_search_by_bow_keyframes(_ptr(a[0]), _ptr(a[1]), len(a[0]), _ptr(a[2]), _ptr(a[3]), _ptr(a[4]), n_1, _ptr(a[5]),
+                                      _ptr(a[6]), len(a[5]), _ptr(a[7]), _ptr(a[8]), _ptr(a[9]), n_2, nn_ratio,
+                                      int(check_orientation), _ptr(match))
+    return n, match[:n_1]
+
+
 class Vocabulary:
     """A DBoW2 vocabulary tree in the oracle (TemplatedVocabulary, reference
     Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h).  Arrays are per node, entry 0 = root."""

@@ -27,6 +27,35 @@ def run_device(ex, kf, f, nn_ratio, check):
     return out
 
 
+def run_device_keyframes(ex, k1, k2, nn_ratio, check):
+    """k1, k2 = (fv_node, fv_idx, fv_n, desc, kps, valid) with a leading pair axis; returns (match12 [n][cap_1], nmatches)."""
+    from hip_rt import DeviceArray
+    n, cap_1, cap_2 = k1[0].shape[0], k1[0].shape[1], k2[0].shape[1]
+    d = [DeviceArray.from_host(np.ascontiguousarray(a)) for a in k1 + k2]
+    d_match = DeviceArray((n, cap_1), np.int32, fill_byte=0x55)
+    d_nm = DeviceArray((n,), np.int32, fill_byte=0x55)
+    ex.search_by_bow_keyframes_batch_device(n, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, d[4].ptr, d[5].ptr, cap_1, d[6].ptr,
+                                            d[7].ptr, d[8].ptr, d[9].ptr, d[10].ptr, d[11].ptr, cap_2, nn_ratio, check,
+                                            d_match.ptr, d_nm.ptr, sync=True)
+    out = d_match.to_host(), d_nm.to_host()
+    for a in d + [d_match, d_nm]:
+        a.free()
+    return out
+
+
+def check_keyframes_against_oracle(oracle, k1, k2, nn_ratio, check, match, nm):
+    total = 0
+    for p in range(k1[0].shape[0]):
+        n1, n2 = int(k1[2][p]), int(k2[2][p])
+        exp_n, exp_m = oracle.search_by_bow_keyframes(k1[0][p, :n1], k1[1][p, :n1], k1[3][p], k1[4][p]["angle"], k1[5][p],
+                                                      k2[0][p, :n2], k2[1][p, :n2], k2[3][p], k2[4][p]["angle"], k2[5][p],
+                                                      nn_ratio, check)
+        assert nm[p] == exp_n, "nmatches of pair %d" % p
+        assert (match[p] == exp_m).all(), "matches of pair %d" % p
+        total += exp_n
+    return total
+
+
 def check_against_oracle(oracle, kf, f, counts_f, nn_ratio, check, match, nm):
     total = 0
     for p in range(kf[0].shape[0]):
@@ -68,6 +97,11 @@ def test_bow_match_after_extraction(oracle, k, L, levelsup, check, seed):
     match, nm = run_device(ex, kf, f, 0.7, check)
     total = check_against_oracle(oracle, kf, f, counts[nxt], 0.7, check, match, nm)
     assert total > 100          # the views do share features
+    # the same views as two keyframes (the loop closer's overload)
+    valid2 = (rng.random((n, cap)) < 0.85).astype(np.uint8)
+    k2 = f + (valid2[nxt],)
+    match12, nm12 = run_device_keyframes(ex, kf, k2, 0.75, check)
+    assert check_keyframes_against_oracle(oracle, kf, k2, 0.75, check, match12, nm12) > 80
     voc.close()
     ex.close()
     for a in (d_frames, d_kps, d_desc, d_n):
@@ -126,10 +160,14 @@ def test_bow_match_crowded_nodes(oracle, n_kf, n_f, cap, n_nodes, flip, seed):
         pairs.append((kf_side + (valid,), f_side))
     kf = tuple(np.stack([pairs[p][0][i] for p in range(2)]) for i in range(6))
     f = tuple(np.stack([pairs[p][1][i] for p in range(2)]) for i in range(5))
+    valid2 = np.zeros((2, cap), np.uint8)
+    valid2[:, :n_f] = rng.random((2, n_f)) < 0.9
     for check in (False, True):
         match, nm = run_device(ex, kf, f, 0.75, check)
         total = check_against_oracle(oracle, kf, f, [n_f, n_f], 0.75, check, match, nm)
         assert total > 10
+        match12, nm12 = run_device_keyframes(ex, kf, f + (valid2,), 0.75, check)
+        assert check_keyframes_against_oracle(oracle, kf, f + (valid2,), 0.75, check, match12, nm12) > 10
     ex.close()
 
 

@@ -1,6 +1,6 @@
-"""Known-answer tests of the oracle's restatement of ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...)
-(reference src/ORBmatcher.cc:159-290): every case is small enough to be worked out by hand from the
-reference's loop."""
+"""Known-answer tests of the oracle's restatements of ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...)
+(reference src/ORBmatcher.cc:159-290) and ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, ...) (:551-684): every
+case is small enough to be worked out by hand from the reference's loops."""
 import numpy as np
 
 
@@ -114,3 +114,40 @@ def test_rotation_histogram_keeps_the_main_bins(oracle):
     # without the check nothing is removed
     n, m = run(oracle, kf, f, check=False)
     assert n == 13
+
+
+def run_kf(oracle, kf1, kf2, nn_ratio=0.7, check=False):
+    """kf1 / kf2: lists of (node, descriptor, angle[, valid]) per feature."""
+    def side(feats):
+        node = np.array([x[0] for x in feats], np.uint32)
+        order = np.lexsort((np.arange(len(feats)), node))
+        desc = np.stack([x[1] for x in feats]) if feats else np.zeros((0, 32), np.uint8)
+        ang = np.array([x[2] for x in feats], np.float32)
+        valid = np.array([x[3] if len(x) > 3 else 1 for x in feats], np.uint8)
+        return node[order], order.astype(np.uint32), desc, ang, valid
+    a, b = side(kf1), side(kf2)
+    return oracle.search_by_bow_keyframes(a[0], a[1], a[2], a[3], a[4], b[0], b[1], b[2], b[3], b[4], nn_ratio, check)
+
+
+def test_keyframe_pair_differences_from_the_frame_version(oracle):
+    z = np.zeros(32, np.uint8)
+    # the threshold is strict here: 50 is rejected, 49 accepted (:627)
+    n, m = run_kf(oracle, [(1, z, 0.0)], [(1, desc_with_bits(50), 0.0)])
+    assert n == 0 and list(m) == [-1]
+    n, m = run_kf(oracle, [(1, z, 0.0)], [(1, desc_with_bits(49), 0.0)])
+    assert n == 1 and list(m) == [0]
+    # the result is indexed by the FIRST keyframe's features and holds the second keyframe's feature (:631)
+    n, m = run_kf(oracle, [(2, z, 0.0), (1, z, 0.0)], [(1, desc_with_bits(3), 0.0), (7, z, 0.0), (2, desc_with_bits(1), 0.0)])
+    assert n == 2 and list(m) == [2, 0]
+    # features of the second keyframe without a good map point are not candidates (:603-609): the twin is
+    # invisible, the other candidate at distance 40 is taken with the second best at 256
+    n, m = run_kf(oracle, [(1, z, 0.0)], [(1, z, 0.0, 0), (1, desc_with_bits(40), 0.0)])
+    assert n == 1 and list(m) == [1]
+    # a feature of the second keyframe serves one feature of the first only (vbMatched2, :605, :632)
+    n, m = run_kf(oracle, [(1, z, 0.0), (1, z, 0.0)], [(1, z, 0.0)])
+    assert n == 1 and list(m) == [0, -1]
+    # the rotation check clears entries of the first keyframe (:663-682): eleven at 0 degrees, one at 90
+    kf1 = [(10 + i, z, 0.0 if i < 11 else 90.0) for i in range(12)]
+    kf2 = [(10 + i, z, 0.0) for i in range(12)]
+    n, m = run_kf(oracle, kf1, kf2, check=True)
+    assert n == 11 and m[11] == -1 and list(m[:11]) == list(range(11))
