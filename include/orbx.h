@@ -183,6 +183,20 @@ int orbx_undistort_grid_batch_device(orbx_ctx* ctx, int n, const orbx_kp* d_kps,
                                      orbx_kp* d_kps_un, int32_t* d_cell_start, int32_t* d_cell_idx,
                                      int sync);
 
+/* ---- RGB-D frames: depth per keypoint ------------------------------------------------------
+ * Replaces Frame::ComputeStereoFromRGBD (reference src/Frame.cc:662-682) together with the depth map's
+ * conversion in Tracking::GrabImageRGBD (src/Tracking.cc:230-231, imDepth.convertTo(imDepth, CV_32F,
+ * mDepthMapFactor)) for every frame of a batch: feature i samples the depth map at the truncated
+ * coordinates of mvKeys[i], d = sample * depth_map_factor (float32; pass Tracking's mDepthMapFactor, i.e.
+ * 1.0f / the settings' DepthMapFactor, or 1), and d > 0 gives d_depth_out = d, d_u_right =
+ * mvKeysUn[i].pt.x - mbf / d; other features and the slots from d_n[f] to kp_cap get -1.  The depth
+ * frames are 16-bit unsigned (depth_is_f32 = 0, the TUM PNGs) or float32 samples in device memory, rows
+ * stride_bytes apart.  Only the sampled values are converted: the converted map has no other reader. */
+int orbx_rgbd_depth_batch_device(orbx_ctx* ctx, int n, const void* d_depth, int depth_is_f32, int width, int height,
+                                 int stride_bytes, size_t frame_stride_bytes, float depth_map_factor, const orbx_kp* d_kps,
+                                 const orbx_kp* d_kps_un, int kp_cap, const int32_t* d_n, float mbf, float* d_u_right,
+                                 float* d_depth_out, int sync);
+
 /* ---- descriptor consumer: the bag-of-words transform -------------------------------------
  * Replaces Frame::ComputeBoW (reference src/Frame.cc:411-418), i.e.
  * ORBVocabulary::transform(descriptors, mBowVec, mFeatVec, 4) of the vendored DBoW2 (reference

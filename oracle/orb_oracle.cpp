@@ -1658,3 +1658,26 @@ extern "C" int orc_search_by_bow_keyframes(const uint32_t* fv_node_1, const uint
     }
     return nmatches;
 }
+
+// Frame::ComputeStereoFromRGBD (reference src/Frame.cc:662-682) on a depth map that Tracking::GrabImageRGBD
+// would convert with imDepth.convertTo(imDepth, CV_32F, mDepthMapFactor) (src/Tracking.cc:230-231; OpenCV 3.4.5's
+// 16u -> 32f and 32f -> 32f scale conversions compute sample * (float)alpha + 0 in float32).  kps_xy: mvKeys
+// (x, y) pairs; un_x: mvKeysUn[i].pt.x.
+extern "C" void orc_stereo_from_rgbd(const void* depth, int is_f32, int width, int height, int stride_bytes, float factor,
+                                     const float* kps_xy, const float* un_x, int n, float mbf, float* u_right,
+                                     float* depth_out) {
+    for (int i = 0; i < n; i++) {
+        u_right[i] = -1.0f;  // :664-665
+        depth_out[i] = -1.0f;
+        const float u = kps_xy[2 * i], v = kps_xy[2 * i + 1];  // :672-673
+        const int x = (int)u, y = (int)v;                      // at<float>(v, u): float -> int truncates
+        if (x < 0 || x >= width || y < 0 || y >= height) continue;
+        const uint8_t* row = (const uint8_t*)depth + (size_t)y * stride_bytes;
+        const float raw = is_f32 ? ((const float*)row)[x] : (float)((const uint16_t*)row)[x];
+        const float d = raw * factor;
+        if (d > 0) {  // :677-681
+            depth_out[i] = d;
+            u_right[i] = un_x[i] - mbf / d;
+        }
+    }
+}

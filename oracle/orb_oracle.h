@@ -278,6 +278,11 @@ int orc_search_by_bow_keyframes(const uint32_t* fv_node_1, const uint32_t* fv_id
                                 const uint32_t* fv_idx_2, int fv_n_2, const uint8_t* desc_2, const float* angle_2,
                                 const uint8_t* valid_2, int n_2, float nn_ratio, int check_orientation, int32_t* match12);
 
+/* Frame::ComputeStereoFromRGBD (reference src/Frame.cc:662-682) incl. the depth conversion of
+ * Tracking::GrabImageRGBD (src/Tracking.cc:230-231). */
+void orc_stereo_from_rgbd(const void* depth, int is_f32, int width, int height, int stride_bytes, float factor,
+                          const float* kps_xy, const float* un_x, int n, float mbf, float* u_right, float* depth_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,7 +54,7 @@ EXPORTS = [
     "orbx_voc_create", "orbx_voc_load_text", "orbx_voc_destroy", "orbx_voc_info", "orbx_voc_node", "orbx_bow_transform_batch_device", "orbx_search_window_batch_device",
     "orbx_search_by_projection_batch_device", "orbx_set_debug_flag",
     "orbx_stereo_match_batch_device_noalloc", "orbx_search_local_map_batch_device", "orbx_search_by_bow_batch_device",
-    "orbx_search_by_bow_keyframes_batch_device",
+    "orbx_search_by_bow_keyframes_batch_device", "orbx_rgbd_depth_batch_device",
 ]
 
 _lib = None
@@ -97,6 +97,7 @@ def load_library():
     L.orbx_search_by_projection_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32]
     L.orbx_search_local_map_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, vp, i32, vp,
                                                      vp, vp, vp, i32]
+    L.orbx_rgbd_depth_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, i32, C.c_size_t, f32, vp, vp, i32, vp, f32, vp, vp, i32]
     L.orbx_search_by_bow_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, f32, i32, vp, vp, i32]
     L.orbx_search_by_bow_keyframes_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, f32,
                                                             i32, vp, vp, i32]
@@ -373,6 +374,15 @@ class ORBextractor:
             C.c_void_p(d_u_right or None), C.c_void_p(d_taken or None), min_x, min_y, inv_w, inv_h, th, nn_ratio,
             C.c_void_p(d_queries), q_cap, C.c_void_p(d_nq), C.c_void_p(d_match), C.c_void_p(d_query_match),
             C.c_void_p(d_nmatches), int(sync)), self._ctx)
+
+    def rgbd_depth_batch_device(self, n, d_depth, depth_is_f32, width, height, stride_bytes, frame_stride_bytes,
+                                depth_map_factor, d_kps, d_kps_un, kp_cap, d_n, mbf, d_u_right, d_depth_out, sync=True):
+        """Frame::ComputeStereoFromRGBD (src/Frame.cc:662-682) with the depth conversion of Tracking::GrabImageRGBD for a
+        batch of frames; raw device addresses; see orbx_rgbd_depth_batch_device."""
+        _check(self._L.orbx_rgbd_depth_batch_device(
+            self._ctx, n, C.c_void_p(d_depth), int(depth_is_f32), width, height, stride_bytes, frame_stride_bytes,
+            depth_map_factor, C.c_void_p(d_kps), C.c_void_p(d_kps_un), kp_cap, C.c_void_p(d_n), mbf, C.c_void_p(d_u_right),
+            C.c_void_p(d_depth_out), int(sync)), self._ctx)
 
     def search_by_bow_batch_device(self, n, d_fv_node_kf, d_fv_idx_kf, d_fv_n_kf, d_desc_kf, d_kps_kf, d_valid_kf, kp_cap_kf,
                                    d_fv_node_f, d_fv_idx_f, d_fv_n_f, d_desc_f, d_kps_f, kp_cap_f, nn_ratio, check_orientation,

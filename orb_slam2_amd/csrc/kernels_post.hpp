@@ -113,5 +113,43 @@ __global__ __launch_bounds__(256) void k_undistort_grid(PostParams P, const orbx
     }
 }
 
+// Frame::ComputeStereoFromRGBD (reference src/Frame.cc:662-682) with the depth map's conversion of
+// Tracking::GrabImageRGBD (src/Tracking.cc:230-231: imDepth.convertTo(imDepth, CV_32F, mDepthMapFactor), one float32
+// multiply per sample) applied to the sampled values only: feature i reads the depth at (int)v, (int)u of its
+// keypoint (cv::Mat::at<float>(float, float) truncates), d > 0 gives mvDepth[i] = d and
+// mvuRight[i] = mvKeysUn[i].pt.x - mbf / d, else both are -1.
+struct RgbdDev {
+    const void* depth;      // [n] frames of `height` rows, `stride` bytes apart; 16-bit unsigned or float32 samples
+    size_t frame_stride;    // bytes
+    int is_f32, width, height, stride;
+    float factor, mbf;
+    const orbx_kp *kps, *kps_un;  // [n][kp_cap]
+    const int32_t* n_kp;          // [n]
+    int kp_cap;
+    float *u_right, *depth_out;   // [n][kp_cap]
+};
+
+// grid = (ceil(kp_cap / 256), frames), block = 256: one thread per feature slot.
+__global__ __launch_bounds__(256) void k_rgbd_depth(RgbdDev D) {
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= D.kp_cap) return;
+    float ur = -1.0f, z = -1.0f;  // :664-665
+    if (i < D.n_kp[f]) {
+        const orbx_kp kp = D.kps[(size_t)f * D.kp_cap + i];
+        const int x = (int)kp.x, y = (int)kp.y;  // :672-675
+        if (x >= 0 && x < D.width && y >= 0 && y < D.height) {  // (every keypoint lies inside its image)
+            const uint8_t* row = (const uint8_t*)D.depth + (size_t)f * D.frame_stride + (size_t)y * D.stride;
+            const float raw = D.is_f32 ? reinterpret_cast<const float*>(row)[x] : (float)reinterpret_cast<const uint16_t*>(row)[x];
+            const float d = __fmul_rn(raw, D.factor);
+            if (d > 0.0f) {  // :677-681
+                z = d;
+                ur = __fsub_rn(D.kps_un[(size_t)f * D.kp_cap + i].x, __fdiv_rn(D.mbf, d));
+            }
+        }
+    }
+    D.u_right[(size_t)f * D.kp_cap + i] = ur;
+    D.depth_out[(size_t)f * D.kp_cap + i] = z;
+}
+
 }  // namespace orbx
 #endif

@@ -1629,6 +1629,38 @@ extern "C" int orbx_search_by_bow_keyframes_batch_device(orbx_ctx* c, int n, con
                          sync);
 }
 
+extern "C" int orbx_rgbd_depth_batch_device(orbx_ctx* c, int n, const void* d_depth, int depth_is_f32, int width, int height,
+                                            int stride_bytes, size_t frame_stride_bytes, float depth_map_factor,
+                                            const orbx_kp* d_kps, const orbx_kp* d_kps_un, int kp_cap, const int32_t* d_n,
+                                            float mbf, float* d_u_right, float* d_depth_out, int sync) {
+    const int sample = depth_is_f32 ? 4 : 2;
+    if (!c || !d_depth || !d_kps || !d_kps_un || !d_n || !d_u_right || !d_depth_out || n < 1 || kp_cap < 1 || width < 1 ||
+        height < 1 || stride_bytes < width * sample || stride_bytes % sample || frame_stride_bytes % (size_t)sample ||
+        ((uintptr_t)d_depth % (uintptr_t)sample) || (n > 1 && frame_stride_bytes < (size_t)height * stride_bytes))
+        return ORBX_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    { int rc_ = join(c); if (rc_) return rc_; }
+    RgbdDev D;
+    D.depth = d_depth;
+    D.frame_stride = frame_stride_bytes;
+    D.is_f32 = depth_is_f32 ? 1 : 0;
+    D.width = width;
+    D.height = height;
+    D.stride = stride_bytes;
+    D.factor = depth_map_factor;
+    D.mbf = mbf;
+    D.kps = d_kps;
+    D.kps_un = d_kps_un;
+    D.n_kp = d_n;
+    D.kp_cap = kp_cap;
+    D.u_right = d_u_right;
+    D.depth_out = d_depth_out;
+    hipLaunchKernelGGL(k_rgbd_depth, dim3((kp_cap + 255) / 256, n), dim3(256), 0, c->stream, D);
+    HIP_TRY(c, hipGetLastError());
+    if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
+    return ORBX_OK;
+}
+
 extern "C" int orbx_synchronize(orbx_ctx* c) {
     if (!c) return ORBX_E_INVALID;
     { int rc_ = sync_ctx(c); if (rc_) return rc_; }

@@ -97,8 +97,23 @@ def make_projection(name, img0, depth0, img1, depth1):
     print(name, "map points", int(ok.sum()), "of", n0, "features", len(cur["kps"]), "nmatches", n)
 
 
+def make_rgbd(name, img, depth):
+    """One RGB-D frame of the sequence: the raw 16-bit depth map and what Frame::ComputeStereoFromRGBD
+    (src/Frame.cc:662-682) makes of it for the frame's keypoints, with the TUM1 settings (DepthMapFactor 5000, so
+    Tracking multiplies the samples by 1.0f / 5000.0f; Camera.bf 40)."""
+    orc = oracle_lib.Oracle(1000, 1.2, 8, 20, 7)
+    kps, _ = orc.extract(img)
+    xy = np.stack([kps["x"], kps["y"]], 1).astype(np.float32)
+    un = oracle_lib.undistort_points(xy, TUM1_K, TUM1_DIST)
+    factor = np.float32(1.0) / np.float32(TUM1_DEPTH_FACTOR)
+    ur, z = oracle_lib.stereo_from_rgbd(depth, factor, xy, un[:, 0], TUM1_BF)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), image=img, depth=depth, K=TUM1_K, dist=TUM1_DIST,
+                        factor=factor, mbf=np.float32(TUM1_BF), u_right=ur, depth_out=z, n=len(kps))
+    print(name, "K =", len(kps), "with depth:", int((z > 0).sum()))
+
+
 if __name__ == "__main__":
-    only = sys.argv[1] if len(sys.argv) > 1 else ""   # "extractor" or "projection": regenerate one family only
+    only = sys.argv[1] if len(sys.argv) > 1 else ""   # "extractor", "projection" or "rgbd": regenerate one family only
     if only in ("", "extractor"):
         make("synth_400x300_f600_l6", synth.make_frame(400, 300, 11, 0), 600, 6)
     ref_dir = "/root/reference/Examples/Monocular/rgbd_dataset_freiburg1_xyz/rgb"
@@ -108,6 +123,11 @@ if __name__ == "__main__":
             f = sorted(os.listdir(ref_dir))[0]
             gray = np.asarray(Image.open(os.path.join(ref_dir, f)).convert("L"), dtype=np.uint8)
             make("tum_fr1_xyz_" + f.replace(".png", "").replace(".", "_") + "_f1000_l8", gray, 1000, 8)
+        if only in ("", "rgbd"):
+            seq = os.path.dirname(ref_dir)
+            r = open("/root/reference/Examples/RGB-D/associations/fr1_xyz.txt").readline().split()
+            make_rgbd("rgbd_tum_fr1_xyz_frame_0", np.asarray(Image.open(os.path.join(seq, r[1])).convert("L"), dtype=np.uint8),
+                      np.asarray(Image.open(os.path.join(seq, r[3])), dtype=np.uint16))
         if only not in ("", "projection"):
             sys.exit(0)
         # the first two associated (rgb, depth) pairs of Examples/RGB-D/associations/fr1_xyz.txt

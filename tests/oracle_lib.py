@@ -393,6 +393,24 @@ def search_local_map(xy, octave, desc, u_right, taken0, cell_start, cell_idx, sc
     return n, match[:n_kp], qmatch[:len(q)]
 
 
+def stereo_from_rgbd(depth, factor, kps_xy, un_x, mbf):
+    """Frame::ComputeStereoFromRGBD on a 2-D depth map (uint16 or float32) that GrabImageRGBD would scale by `factor`;
+    returns (mvuRight, mvDepth)."""
+    L = lib()
+    L.orc_stereo_from_rgbd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                                       C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    L.orc_stereo_from_rgbd.restype = None
+    depth = np.ascontiguousarray(depth)
+    assert depth.dtype in (np.uint16, np.float32) and depth.ndim == 2
+    xy = np.ascontiguousarray(kps_xy, np.float32)
+    ux = np.ascontiguousarray(un_x, np.float32)
+    n = len(ux)
+    ur, z = np.zeros(max(n, 1), np.float32), np.zeros(max(n, 1), np.float32)
+    L.orc_stereo_from_rgbd(_ptr(depth), int(depth.dtype == np.float32), depth.shape[1], depth.shape[0], depth.strides[0],
+                           factor, _ptr(xy), _ptr(ux), n, mbf, _ptr(ur), _ptr(z))
+    return ur[:n], z[:n]
+
+
 def search_by_bow(fv_node_kf, fv_idx_kf, desc_kf, angle_kf, valid_kf, fv_node_f, fv_idx_f, desc_f, angle_f, nn_ratio,
                   check_orientation):
     """ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) (reference src/ORBmatcher.cc:159-290) on FeatureVectors

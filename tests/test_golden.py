@@ -10,8 +10,9 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ALL = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
-FILES = [f for f in ALL if not os.path.basename(f).startswith("projection_")]      # extractor fixtures
+FILES = [f for f in ALL if not os.path.basename(f).startswith(("projection_", "rgbd_"))]   # extractor fixtures
 PROJ = [f for f in ALL if os.path.basename(f).startswith("projection_")]           # SearchByProjection fixtures
+RGBD = [f for f in ALL if os.path.basename(f).startswith("rgbd_")]                 # ComputeStereoFromRGBD fixtures
 
 
 def _sha(a):
@@ -129,4 +130,58 @@ def test_hip_reproduces_projection_golden(path):
     assert np.array_equal(d_qm.to_host()[0], g["query_match"])
     ex.close()
     for a in (d_img, d_kps, d_desc, d_n, d_un, d_cs, d_ci, d_ur, d_q, d_nq, d_poses, d_match, d_qm, d_nm):
+        a.free()
+
+
+# ---- Frame::ComputeStereoFromRGBD on a real RGB-D frame (tests/golden/rgbd_*.npz: the raw 16-bit depth map of
+# ---- the reference's bundled TUM sequence) ----
+def test_rgbd_fixture_present():
+    assert len(RGBD) >= 1
+
+
+@pytest.mark.parametrize("path", RGBD, ids=[os.path.basename(f) for f in RGBD])
+def test_oracle_reproduces_rgbd_golden(oracle, path):
+    g = np.load(path, allow_pickle=False)
+    orc = oracle.Oracle(1000, 1.2, 8, 20, 7)
+    kps, _ = orc.extract(g["image"])
+    assert len(kps) == int(g["n"])
+    xy = np.stack([kps["x"], kps["y"]], 1).astype(np.float32)
+    un = oracle.undistort_points(xy, g["K"], g["dist"])
+    ur, z = oracle.stereo_from_rgbd(g["depth"], float(g["factor"]), xy, un[:, 0], float(g["mbf"]))
+    assert (ur.view(np.uint32) == g["u_right"].view(np.uint32)).all() and (z.view(np.uint32) == g["depth_out"].view(np.uint32)).all()
+    # the depth the fixture stores is the sample times the float reciprocal of 5000, not the sample divided by 5000
+    has = z > 0
+    raw = g["depth"][kps["y"].astype(np.int32), kps["x"].astype(np.int32)].astype(np.float32)
+    assert (z[has] == raw[has] * np.float32(g["factor"])).all() and has.sum() > 500
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", RGBD, ids=[os.path.basename(f) for f in RGBD])
+def test_hip_reproduces_rgbd_golden(path):
+    import orb_slam2_amd as oa
+    from hip_rt import DeviceArray
+    g = np.load(path, allow_pickle=False)
+    img, depth = g["image"], g["depth"]
+    h, w = img.shape
+    ex = oa.ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1, keep_pyramid=False)
+    cap = ex.max_keypoints(w, h)
+    d_img, d_depth = DeviceArray.from_host(img), DeviceArray.from_host(depth)
+    d_kps, d_un = DeviceArray((1, cap), oa.KP_DTYPE), DeviceArray((1, cap), oa.KP_DTYPE)
+    d_desc = DeviceArray((1, cap, 32), np.uint8)
+    d_n = DeviceArray((1,), np.int32, fill_byte=0)
+    d_cs, d_ci = DeviceArray((1, 64 * 48 + 1), np.int32), DeviceArray((1, cap), np.int32)
+    d_ur, d_z = DeviceArray((1, cap), np.float32, fill_byte=0x55), DeviceArray((1, cap), np.float32, fill_byte=0x55)
+    ex.extract_batch_device(d_img.ptr, 1, w, h, w, w * h, d_kps.ptr, cap, d_desc.ptr, d_n.ptr, sync=False)
+    ex.undistort_grid_batch_device(1, d_kps.ptr, cap, d_n.ptr, g["K"], g["dist"], 0.0, 0.0, 0.1, 0.1, d_un.ptr, d_cs.ptr, d_ci.ptr,
+                                   sync=False)
+    ex.rgbd_depth_batch_device(1, d_depth.ptr, False, w, h, 2 * w, 2 * w * h, float(g["factor"]), d_kps.ptr, d_un.ptr, cap,
+                               d_n.ptr, float(g["mbf"]), d_ur.ptr, d_z.ptr, sync=True)
+    n = int(d_n.to_host()[0])
+    assert n == int(g["n"])
+    ur, z = d_ur.to_host()[0], d_z.to_host()[0]
+    assert (ur[:n].view(np.uint32) == g["u_right"].view(np.uint32)).all()
+    assert (z[:n].view(np.uint32) == g["depth_out"].view(np.uint32)).all()
+    assert (ur[n:] == -1).all() and (z[n:] == -1).all()
+    ex.close()
+    for a in (d_img, d_depth, d_kps, d_un, d_desc, d_n, d_cs, d_ci, d_ur, d_z):
         a.free()
