@@ -59,10 +59,9 @@ def frame_of(img, depth):
     min_y, max_y = min(c[0, 1], c[1, 1]), max(c[2, 1], c[3, 1])
     inv_w, inv_h = np.float32(64) / np.float32(max_x - min_x), np.float32(48) / np.float32(max_y - min_y)
     start, idx = oracle_lib.assign_grid(un, min_x, min_y, inv_w, inv_h)
-    d = depth[kps["y"].astype(np.int32), kps["x"].astype(np.int32)].astype(np.float32) / np.float32(TUM1_DEPTH_FACTOR)
-    has = d > 0
-    u_right = np.where(has, un[:, 0] - np.float32(TUM1_BF) / np.where(has, d, 1).astype(np.float32), -1).astype(np.float32)
-    return dict(kps=kps, desc=desc, un=un, start=start, idx=idx, depth=np.where(has, d, -1).astype(np.float32), u_right=u_right,
+    # the samples times Tracking's mDepthMapFactor = 1.0f / 5000 (src/Tracking.cc:145-149, 230-231)
+    u_right, d = oracle_lib.stereo_from_rgbd(depth, np.float32(1.0) / np.float32(TUM1_DEPTH_FACTOR), xy, un[:, 0], TUM1_BF)
+    return dict(kps=kps, desc=desc, un=un, start=start, idx=idx, depth=d, u_right=u_right,
                 bounds=np.array([min_x, min_y, max_x, max_y, inv_w, inv_h], np.float32),
                 scale=np.array(orc.params.scale[:8], np.float32))
 
