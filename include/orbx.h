@@ -357,6 +357,27 @@ int orbx_search_by_bow_keyframes_batch_device(orbx_ctx* ctx, int n, const uint32
                                               const orbx_kp* d_kps_2, const uint8_t* d_valid_2, int kp_cap_2, float nn_ratio,
                                               int check_orientation, int32_t* d_match12, int32_t* d_nmatches, int sync);
 
+/* ---- descriptor consumer: the matcher of the monocular initialisation ----------------------
+ * Replaces ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, vector<cv::Point2f>& vbPrevMatched,
+ * vector<int>& vnMatches12, int windowSize) (reference src/ORBmatcher.cc:418-549; called from
+ * Tracking::MonocularInitialization, src/Tracking.cc:667, with windowSize 100 and an ORBmatcher(0.9, true))
+ * for a batch of (F1, F2) pairs.  Every level-0 keypoint i of F1 searches the square window of half side
+ * window_size around d_prev_matched[f*kp_cap_1 + i] (x, y) among F2's level-0 features (F2's undistorted
+ * keypoints, grid and descriptors as orbx_undistort_grid_batch_device leaves them; the grid geometry as in
+ * orbx_search_window_batch_device), skips features an earlier keypoint holds with a distance at least as
+ * small, accepts a best distance <= 50 (TH_LOW) below nn_ratio times the second best, and takes the
+ * feature away from its previous holder; the rotation histogram keeps the three main bins when
+ * check_orientation is set.  Outputs: d_match12[f*kp_cap_1 + i] = vnMatches12[i] (-1 also beyond
+ * d_n_1[f]), d_nmatches[f] = the return value, and d_prev_matched is updated in place with the matched
+ * F2 keypoints' positions (:544-546).  kp_cap_1, kp_cap_2 <= 8192; descriptors 16-byte aligned. */
+int orbx_search_for_initialization_batch_device(orbx_ctx* ctx, int n, const orbx_kp* d_kps_un_1, const uint8_t* d_desc_1,
+                                                const int32_t* d_n_1, int kp_cap_1, float* d_prev_matched,
+                                                const orbx_kp* d_kps_un_2, const int32_t* d_cell_start_2,
+                                                const int32_t* d_cell_idx_2, const uint8_t* d_desc_2, int kp_cap_2,
+                                                float min_x, float min_y, float inv_w, float inv_h, int window_size,
+                                                float nn_ratio, int check_orientation, int32_t* d_match12,
+                                                int32_t* d_nmatches, int sync);
+
 /* ---- the stage after the extractor: stereo association ---------------------------------
  * Replaces Frame::ComputeStereoMatches (reference src/Frame.cc:485-659, descriptor distance
  * src/ORBmatcher.cc:1684-1700): for every left keypoint the best right keypoint in its row
@@ -429,7 +450,8 @@ enum {
     ORBX_FLAG_STEREO_BORDER_PATH = 3, /* every stereo window through the reflecting byte loader      */
     ORBX_FLAG_TRACE = 4,              /* timing prints of the host batch path on stderr              */
     ORBX_FLAG_NO_GRAPH = 5,           /* orbx_extract issues its launches one by one, no HIP graph   */
-    ORBX_FLAG_PIPE_CHUNK = 6          /* frames per chunk of the pipelined host batch path (0: auto) */
+    ORBX_FLAG_PIPE_CHUNK = 6,         /* frames per chunk of the pipelined host batch path (0: auto) */
+    ORBX_FLAG_INIT_LIST = 7           /* candidates per list of orbx_search_for_initialization_batch_device (0: default) */
 };
 int orbx_set_debug_flag(orbx_ctx* ctx, int flag, int value);
 

@@ -1681,3 +1681,103 @@ extern "C" void orc_stereo_from_rgbd(const void* depth, int is_f32, int width, i
         }
     }
 }
+
+// ORBmatcher::SearchForInitialization (reference src/ORBmatcher.cc:418-549), the matcher of the monocular
+// initialisation (Tracking::MonocularInitialization, src/Tracking.cc:617): every level-0 keypoint of the first
+// frame searches a square window of the second frame around the place it was last matched at.  octave1 / angle1 /
+// desc1: F1.mvKeysUn and descriptors; prev_matched (in and out): vbPrevMatched as (x, y) pairs; the second frame's
+// undistorted keypoints with its grid in CSR form (cell = column * 48 + row).  match12 = vnMatches12; returns
+// nmatches.
+extern "C" int orc_search_for_initialization(const int32_t* octave1, const float* angle1, const uint8_t* desc1, int n1,
+                                             float* prev_matched, const float* kps2_xy, const int32_t* octave2,
+                                             const float* angle2, const uint8_t* desc2, int n2, const int32_t* cell_start2,
+                                             const int32_t* cell_idx2, float min_x, float min_y, float inv_w, float inv_h,
+                                             int window_size, float nn_ratio, int check_orientation, int32_t* match12) {
+    const int HISTO_LENGTH = 30, TH_LOW = 50, COLS = 64, ROWS = 48;
+    int nmatches = 0;                                    // :420
+    for (int i = 0; i < n1; i++) match12[i] = -1;        // :422
+    std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+    const float factor = 1.0f / HISTO_LENGTH;            // :428
+    std::vector<int> vMatchedDistance((size_t)std::max(n2, 1), INT_MAX), vnMatches21((size_t)std::max(n2, 1), -1);  // :430-431
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int level1 = octave1[i1];
+        if (level1 > 0) continue;  // :438
+        // F2.GetFeaturesInArea(vbPrevMatched[i1].x, vbPrevMatched[i1].y, windowSize, level1, level1), src/Frame.cc:338-396
+        const float x = prev_matched[2 * i1], y = prev_matched[2 * i1 + 1], r = (float)window_size;
+        const int minLevel = level1, maxLevel = level1;
+        const int nMinCellX = std::max(0, (int)std::floor((x - min_x - r) * inv_w));
+        if (nMinCellX >= COLS) continue;
+        const int nMaxCellX = std::min(COLS - 1, (int)std::ceil((x - min_x + r) * inv_w));
+        if (nMaxCellX < 0) continue;
+        const int nMinCellY = std::max(0, (int)std::floor((y - min_y - r) * inv_h));
+        if (nMinCellY >= ROWS) continue;
+        const int nMaxCellY = std::min(ROWS - 1, (int)std::ceil((y - min_y + r) * inv_h));
+        if (nMaxCellY < 0) continue;
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        const uint8_t* d1 = desc1 + (size_t)i1 * 32;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;  // :450-452
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                const int c = ix * ROWS + iy;
+                for (int j = cell_start2[c]; j < cell_start2[c + 1]; j++) {
+                    const int i2 = cell_idx2[j];
+                    if (bCheckLevels) {
+                        if (octave2[i2] < minLevel) continue;
+                        if (maxLevel >= 0)
+                            if (octave2[i2] > maxLevel) continue;
+                    }
+                    const float distx = kps2_xy[2 * i2] - x;
+                    const float disty = kps2_xy[2 * i2 + 1] - y;
+                    if (!(std::fabs(distx) < r && std::fabs(disty) < r)) continue;
+                    const int dist = orc_descriptor_distance(d1, desc2 + (size_t)i2 * 32);
+                    if (vMatchedDistance[i2] <= dist) continue;  // :465-466
+                    if (dist < bestDist) {                       // :468-477
+                        bestDist2 = bestDist;
+                        bestDist = dist;
+                        bestIdx2 = i2;
+                    } else if (dist < bestDist2) {
+                        bestDist2 = dist;
+                    }
+                }
+            }
+        if (bestDist <= TH_LOW) {                                // :482
+            if (bestDist < (float)bestDist2 * nn_ratio) {        // :484
+                if (vnMatches21[bestIdx2] >= 0) {                // :486-490
+                    match12[vnMatches21[bestIdx2]] = -1;
+                    nmatches--;
+                }
+                match12[i1] = bestIdx2;                          // :491-495
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (check_orientation) {                         // :497-509
+                    float rot = angle1[i1] - angle2[bestIdx2];
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (check_orientation) {  // :514-540
+        int ind1 = -1, ind2 = -1, ind3 = -1, size[30];
+        for (int i = 0; i < HISTO_LENGTH; i++) size[i] = (int)rotHist[i].size();
+        three_maxima(size, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (size_t j = 0; j < rotHist[i].size(); j++) {
+                    const int idx1 = rotHist[i][j];
+                    if (match12[idx1] >= 0) {  // :532-536
+                        match12[idx1] = -1;
+                        nmatches--;
+                    }
+                }
+    }
+    for (int i1 = 0; i1 < n1; i1++)  // :544-546
+        if (match12[i1] >= 0) {
+            prev_matched[2 * i1] = kps2_xy[2 * match12[i1]];
+            prev_matched[2 * i1 + 1] = kps2_xy[2 * match12[i1] + 1];
+        }
+    return nmatches;
+}

@@ -283,6 +283,13 @@ int orc_search_by_bow_keyframes(const uint32_t* fv_node_1, const uint32_t* fv_id
 void orc_stereo_from_rgbd(const void* depth, int is_f32, int width, int height, int stride_bytes, float factor,
                           const float* kps_xy, const float* un_x, int n, float mbf, float* u_right, float* depth_out);
 
+/* ORBmatcher::SearchForInitialization (reference src/ORBmatcher.cc:418-549); prev_matched is vbPrevMatched, in and out. */
+int orc_search_for_initialization(const int32_t* octave1, const float* angle1, const uint8_t* desc1, int n1,
+                                  float* prev_matched, const float* kps2_xy, const int32_t* octave2, const float* angle2,
+                                  const uint8_t* desc2, int n2, const int32_t* cell_start2, const int32_t* cell_idx2,
+                                  float min_x, float min_y, float inv_w, float inv_h, int window_size, float nn_ratio,
+                                  int check_orientation, int32_t* match12);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,7 @@ assert KP_DTYPE.itemsize == 28
 
 DBG_BLURRED, DBG_CANDIDATES, DBG_LEVEL_KPS = 1, 2, 3
 FLAG_NO_OVERLAP, FLAG_RESIZE_TILES, FLAG_STEREO_BORDER_PATH, FLAG_TRACE, FLAG_NO_GRAPH, FLAG_PIPE_CHUNK = 1, 2, 3, 4, 5, 6
+FLAG_INIT_LIST = 7
 
 
 class OrbxError(RuntimeError):
@@ -55,6 +56,7 @@ EXPORTS = [
     "orbx_search_by_projection_batch_device", "orbx_set_debug_flag",
     "orbx_stereo_match_batch_device_noalloc", "orbx_search_local_map_batch_device", "orbx_search_by_bow_batch_device",
     "orbx_search_by_bow_keyframes_batch_device", "orbx_rgbd_depth_batch_device",
+    "orbx_search_for_initialization_batch_device",
 ]
 
 _lib = None
@@ -101,6 +103,8 @@ def load_library():
     L.orbx_search_by_bow_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, f32, i32, vp, vp, i32]
     L.orbx_search_by_bow_keyframes_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, f32,
                                                             i32, vp, vp, i32]
+    L.orbx_search_for_initialization_batch_device.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, f32, f32, f32,
+                                                              f32, i32, f32, i32, vp, vp, i32]
     L.orbx_gray_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, i32, i32, vp, i32, C.c_size_t, i32]
     L.orbx_remap_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, vp, vp, i32, vp, i32, i32, i32,
                                           C.c_size_t, i32]
@@ -406,6 +410,17 @@ class ORBextractor:
             C.c_void_p(d_kps_1), C.c_void_p(d_valid_1), kp_cap_1, C.c_void_p(d_fv_node_2), C.c_void_p(d_fv_idx_2),
             C.c_void_p(d_fv_n_2), C.c_void_p(d_desc_2), C.c_void_p(d_kps_2), C.c_void_p(d_valid_2), kp_cap_2, nn_ratio,
             int(check_orientation), C.c_void_p(d_match12), C.c_void_p(d_nmatches), int(sync)), self._ctx)
+
+    def search_for_initialization_batch_device(self, n, d_kps_un_1, d_desc_1, d_n_1, kp_cap_1, d_prev_matched, d_kps_un_2,
+                                               d_cell_start_2, d_cell_idx_2, d_desc_2, kp_cap_2, min_x, min_y, inv_w, inv_h,
+                                               window_size, nn_ratio, check_orientation, d_match12, d_nmatches, sync=True):
+        """ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (src/ORBmatcher.cc:418-549)
+        for a batch of frame pairs; d_prev_matched is read and updated.  See orbx_search_for_initialization_batch_device."""
+        _check(self._L.orbx_search_for_initialization_batch_device(
+            self._ctx, n, C.c_void_p(d_kps_un_1), C.c_void_p(d_desc_1), C.c_void_p(d_n_1), kp_cap_1, C.c_void_p(d_prev_matched),
+            C.c_void_p(d_kps_un_2), C.c_void_p(d_cell_start_2), C.c_void_p(d_cell_idx_2), C.c_void_p(d_desc_2), kp_cap_2,
+            min_x, min_y, inv_w, inv_h, int(window_size), nn_ratio, int(check_orientation), C.c_void_p(d_match12),
+            C.c_void_p(d_nmatches), int(sync)), self._ctx)
 
     # ---- the stage after the extractor: Frame::ComputeStereoMatches (src/Frame.cc:485-659) ----
     def stereo_match(self, right, mb, mbf, img_left=0, img_right=0):

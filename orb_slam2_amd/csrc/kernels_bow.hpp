@@ -264,7 +264,16 @@ struct WindowDev {
 // the minimum of (distance, entry number).  All sixteen lanes of a group call this together; each
 // receives the winner (-1: none) and its key (distance in bits 23..31, 0xFFFFFFFF: none).
 // held(i2) tells whether feature i2 holds a map point the query must respect;
-// on_cand(i2, dist, key, octave) runs for every candidate that passes the filters.
+// on_cand(i2, dist, key, keypoint) runs for every candidate that passes the filters.
+template <int CTRL>
+__device__ __forceinline__ void window_min_dpp(uint32_t& k, int& v) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k, CTRL, 0xF, 0xF, false);
+    const int w = __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+    const bool take = o < k;
+    k = take ? o : k;
+    v = take ? w : v;
+}
+
 template <class Held, class OnCand>
 __device__ __forceinline__ void window_best(const WindowDev& W, int f, float x, float y, float r, float ur, int minLevel,
                                             int maxLevel, const uint4& d0, const uint4& d1, int sub, Held held,
@@ -327,7 +336,7 @@ __device__ __forceinline__ void window_best(const WindowDev& W, int f, float x, 
                                               __popc(d0.w ^ da.w) + __popc(d1.x ^ db.x) + __popc(d1.y ^ db.y) +
                                               __popc(d1.z ^ db.z) + __popc(d1.w ^ db.w);
                         const uint32_t kc = (dist << 23) | (order0 + (uint32_t)e);
-                        on_cand(i2, dist, kc, kp.octave);
+                        on_cand(i2, dist, kc, kp);
                         if (dist < 256u && kc < key) {  // bestDist starts at 256, strict "<" (:1456)
                             key = kc;
                             mine = i2;
@@ -338,12 +347,14 @@ __device__ __forceinline__ void window_best(const WindowDev& W, int f, float x, 
             order0 += (uint32_t)total;
         }
     }
+    // the group's smallest key with its feature, through the row's DPP network (keys are unique: the entry
+    // number is part of them; lanes without a candidate hold 0xFFFFFFFF and -1)
     uint32_t kmin = key;
-#pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d, 64));
-    // keys are unique (the entry number is), so one lane of the group holds the minimum
-    const uint32_t owners = (uint32_t)(__ballot(key == kmin) >> gbase) & 0xFFFFu;
-    const int win = __shfl(mine, gbase + __ffs((int)owners) - 1, 64);
+    int win = mine;
+    window_min_dpp<0xB1>(kmin, win);   // quad_perm [1,0,3,2]
+    window_min_dpp<0x4E>(kmin, win);   // quad_perm [2,3,0,1]
+    window_min_dpp<0x141>(kmin, win);  // row_half_mirror
+    window_min_dpp<0x140>(kmin, win);  // row_mirror
     *win_out = kmin == 0xFFFFFFFFu ? -1 : win;
     *key_out = kmin;
 }
@@ -361,7 +372,7 @@ __global__ __launch_bounds__(256) void k_search_window(WindowDev W, const Window
     uint32_t kmin;
     const uint8_t* taken = W.taken ? W.taken + (size_t)f * W.kp_cap : nullptr;
     window_best(W, f, Q->u, Q->v, Q->radius, Q->ur, Q->min_level, Q->max_level, d0, d1, sub,
-                [&](int i2) { return taken && taken[i2]; }, [](int, uint32_t, uint32_t, int) {}, &win, &kmin);
+                [&](int i2) { return taken && taken[i2]; }, [](int, uint32_t, uint32_t, const orbx_kp&) {}, &win, &kmin);
     if (sub == 0) {
         const size_t o = (size_t)f * W.q_cap + q;
         best_idx[o] = win;
@@ -541,7 +552,7 @@ __global__ __launch_bounds__(kProjThreads) void k_search_projection(ProjDev D) {
                     int win;
                     uint32_t key;
                     window_best(D.W, f, u, v, radius, ur, lo, hi, d0, d1, sub, [&](int i2) { return held[i2] < q; },
-                                [&](int i2, uint32_t dist, uint32_t kc, int) {
+                                [&](int i2, uint32_t dist, uint32_t kc, const orbx_kp&) {
                                     if (dist > (uint32_t)kThHigh) return;
                                     if (holds) atomicMin(&minq[i2], q);
                                     if (round == 0) {
@@ -706,16 +717,36 @@ struct LocalDev {
 
 // Merges the two smallest keys of another lane into (k1, k2); the values ride along.
 __device__ __forceinline__ void top2_merge(uint32_t& k1, uint32_t& k2, int& v1, int& v2, uint32_t o1, uint32_t o2, int w1, int w2) {
-    if (o1 < k1) {
-        const bool second_mine = k1 < o2;   // the old best or the other lane's second comes next
-        k2 = second_mine ? k1 : o2;
-        v2 = second_mine ? v1 : w2;
-        k1 = o1;
-        v1 = w1;
-    } else if (o1 < k2) {
-        k2 = o1;
-        v2 = w1;
-    }
+    // selects only: conditional stores through the references would keep the four values in memory
+    const bool first = o1 < k1;        // the other lane's best is the new best
+    const bool second_mine = k1 < o2;  // then the old best or the other lane's second comes next
+    const bool middle = o1 < k2;       // else the other lane's best may still be the new second
+    const uint32_t nk2 = first ? (second_mine ? k1 : o2) : (middle ? o1 : k2);
+    const int nv2 = first ? (second_mine ? v1 : w2) : (middle ? w1 : v2);
+    k1 = first ? o1 : k1;
+    v1 = first ? w1 : v1;
+    k2 = nk2;
+    v2 = nv2;
+}
+
+// One step of the merge inside a row of sixteen lanes: the partner lane comes through DPP (no LDS round
+// trip).  Every lane of the row must be active.
+template <int CTRL>
+__device__ __forceinline__ void top2_merge_dpp(uint32_t& k1, uint32_t& k2, int& v1, int& v2) {
+    const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k1, CTRL, 0xF, 0xF, false);
+    const uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k2, CTRL, 0xF, 0xF, false);
+    const int w1 = __builtin_amdgcn_update_dpp(0, v1, CTRL, 0xF, 0xF, false);
+    const int w2 = __builtin_amdgcn_update_dpp(0, v2, CTRL, 0xF, 0xF, false);
+    top2_merge(k1, k2, v1, v2, o1, o2, w1, w2);
+}
+
+// Leaves the two smallest keys of a row of sixteen lanes (with their values) in all of its lanes.  The keys
+// must be unique: every step joins two disjoint sets (lane pairs, quads, halves, the row).
+__device__ __forceinline__ void top2_row_merge(uint32_t& k1, uint32_t& k2, int& v1, int& v2) {
+    top2_merge_dpp<0xB1>(k1, k2, v1, v2);   // quad_perm [1,0,3,2]
+    top2_merge_dpp<0x4E>(k1, k2, v1, v2);   // quad_perm [2,3,0,1]
+    top2_merge_dpp<0x141>(k1, k2, v1, v2);  // row_half_mirror
+    top2_merge_dpp<0x140>(k1, k2, v1, v2);  // row_mirror
 }
 
 // grid = frames, block = 1024 (64 groups of sixteen lanes).
@@ -768,27 +799,13 @@ __global__ __launch_bounds__(kProjThreads) void k_search_local(LocalDev D) {
                 uint32_t key;
                 window_best(D.W, f, m->u, m->v, radius, m->ur, m->level - 1, m->level, d0, d1, sub,
                             [&](int i2) { return held[i2] < q; },
-                            [&](int i2, uint32_t dist, uint32_t kc, int octave) {
+                            [&](int i2, uint32_t dist, uint32_t kc, const orbx_kp& kp) {
                                 if (holds && dist <= (uint32_t)kThHigh) atomicMin(&minq[i2], q);
-                                const int val = i2 | (octave << 20);
-                                if (kc < k1) {
-                                    k2 = k1;
-                                    v2 = v1;
-                                    k1 = kc;
-                                    v1 = val;
-                                } else if (kc < k2) {
-                                    k2 = kc;
-                                    v2 = val;
-                                }
+                                top2_merge(k1, k2, v1, v2, kc, 0xFFFFFFFFu, i2 | (kp.octave << 20), -1);
                             },
                             &win, &key);
                 // the group's two smallest keys (keys are unique: the visiting order is part of them)
-#pragma unroll
-                for (int d = 8; d >= 1; d >>= 1) {
-                    const uint32_t o1 = (uint32_t)__shfl_xor((int)k1, d, 64), o2 = (uint32_t)__shfl_xor((int)k2, d, 64);
-                    const int w1 = __shfl_xor(v1, d, 64), w2 = __shfl_xor(v2, d, 64);
-                    top2_merge(k1, k2, v1, v2, o1, o2, w1, w2);
-                }
+                top2_row_merge(k1, k2, v1, v2);
                 if (k1 != 0xFFFFFFFFu) {
                     const int bestDist = (int)(k1 >> 23), bestLevel = v1 >> 20;
                     const int bestDist2 = k2 == 0xFFFFFFFFu ? 256 : (int)(k2 >> 23), bestLevel2 = k2 == 0xFFFFFFFFu ? -1 : (v2 >> 20);

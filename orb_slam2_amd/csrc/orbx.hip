@@ -18,6 +18,7 @@
 #include "kernels_post.hpp"
 #include "kernels_bow.hpp"
 #include "kernels_bowmatch.hpp"
+#include "kernels_initmatch.hpp"
 #include "kernels_pyramid.hpp"
 #include "kernels_staging.hpp"
 #include "kernels_stereo.hpp"
@@ -147,6 +148,7 @@ struct orbx_ctx {
     // diagnostic switches: read from the environment once, in orbx_create; orbx_set_debug_flag changes them
     bool dbg_no_overlap = false, dbg_resize_tiles = false, dbg_stereo_border = false, dbg_trace = false, dbg_no_graph = false;
     int dbg_pipe_chunk = 0;
+    int dbg_init_list = 0;
     bool dbg_aux_low_priority = false;
     // launch graph of the single-frame host path (captured once per image size, replayed by orbx_extract)
     hipGraphExec_t graph_exec = nullptr;
@@ -1027,6 +1029,9 @@ extern "C" int orbx_create(const orbx_params* params, orbx_ctx** out) {
                            reinterpret_cast<const void*>(k_bow_vectors)})
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds) != hipSuccess)
             return fail(ORBX_E_HIP);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_init), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)init_match_lds_bytes(kInitMaxCap, kInitMaxCap, kInitListCap)) != hipSuccess)
+        return fail(ORBX_E_HIP);
     if ((rc = scratch_address(params->device_id, &c->scratch, &c->last_hip))) return fail(rc);
     {
         std::vector<uint32_t> tab((size_t)kDescTabVec * 64 * 4);
@@ -1629,6 +1634,41 @@ extern "C" int orbx_search_by_bow_keyframes_batch_device(orbx_ctx* c, int n, con
                          sync);
 }
 
+extern "C" int orbx_search_for_initialization_batch_device(orbx_ctx* c, int n, const orbx_kp* d_kps_un_1,
+                                                           const uint8_t* d_desc_1, const int32_t* d_n_1, int kp_cap_1,
+                                                           float* d_prev_matched, const orbx_kp* d_kps_un_2,
+                                                           const int32_t* d_cell_start_2, const int32_t* d_cell_idx_2,
+                                                           const uint8_t* d_desc_2, int kp_cap_2, float min_x, float min_y,
+                                                           float inv_w, float inv_h, int window_size, float nn_ratio,
+                                                           int check_orientation, int32_t* d_match12, int32_t* d_nmatches,
+                                                           int sync) {
+    if (!c || !d_kps_un_1 || !d_desc_1 || !d_n_1 || !d_prev_matched || !d_kps_un_2 || !d_cell_start_2 || !d_cell_idx_2 ||
+        !d_desc_2 || !d_match12 || !d_nmatches || n < 1 || kp_cap_1 < 1 || kp_cap_2 < 1 || window_size < 0 ||
+        !(nn_ratio > 0.0f) || ((uintptr_t)d_desc_1 | (uintptr_t)d_desc_2) % 16 || (uintptr_t)d_prev_matched % 8)
+        return ORBX_E_INVALID;
+    if (kp_cap_1 > kInitMaxCap || kp_cap_2 > kInitMaxCap) return ORBX_E_CAPACITY;  // 16-bit state in LDS
+    HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    { int rc_ = join(c); if (rc_) return rc_; }
+    InitDev D;
+    D.W = {d_kps_un_2, d_cell_start_2, d_cell_idx_2, d_desc_2, nullptr, nullptr, min_x, min_y, inv_w, inv_h, kp_cap_2, 0};
+    D.kps_un_1 = d_kps_un_1;
+    D.desc_1 = d_desc_1;
+    D.n_1 = d_n_1;
+    D.prev_matched = reinterpret_cast<float2*>(d_prev_matched);
+    D.match12 = d_match12;
+    D.n_matches = d_nmatches;
+    D.window = (float)window_size;
+    D.nn_ratio = nn_ratio;
+    D.cap_1 = kp_cap_1;
+    D.check_orientation = check_orientation ? 1 : 0;
+    D.list_cap = c->dbg_init_list > 0 ? c->dbg_init_list : kInitListCap;
+    const size_t lds = init_match_lds_bytes(kp_cap_1, kp_cap_2, D.list_cap);
+    hipLaunchKernelGGL(k_search_init, dim3(n), dim3(kInitThreads), lds, c->stream, D);
+    HIP_TRY(c, hipGetLastError());
+    if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
+    return ORBX_OK;
+}
+
 extern "C" int orbx_rgbd_depth_batch_device(orbx_ctx* c, int n, const void* d_depth, int depth_is_f32, int width, int height,
                                             int stride_bytes, size_t frame_stride_bytes, float depth_map_factor,
                                             const orbx_kp* d_kps, const orbx_kp* d_kps_un, int kp_cap, const int32_t* d_n,
@@ -1755,6 +1795,7 @@ extern "C" int orbx_set_debug_flag(orbx_ctx* c, int flag, int value) {
         case ORBX_FLAG_TRACE: c->dbg_trace = value != 0; break;
         case ORBX_FLAG_NO_GRAPH: c->dbg_no_graph = value != 0; break;
         case ORBX_FLAG_PIPE_CHUNK: c->dbg_pipe_chunk = std::max(0, value); break;
+        case ORBX_FLAG_INIT_LIST: c->dbg_init_list = std::max(0, std::min(value, kInitListCap)); break;
         default: return ORBX_E_INVALID;
     }
     drop_graph(c);  // captured with the old switches

@@ -448,6 +448,33 @@ def search_by_bow_keyframes(fv_node_1, fv_idx_1, desc_1, angle_1, valid_1, fv_no
     return n, match[:n_1]
 
 
+def search_for_initialization(octave_1, angle_1, desc_1, prev_matched, xy_2, octave_2, angle_2, desc_2, cell_start_2,
+                              cell_idx_2, min_x, min_y, inv_w, inv_h, window_size, nn_ratio, check_orientation):
+    """ORBmatcher::SearchForInitialization (reference src/ORBmatcher.cc:418-549); returns (nmatches, vnMatches12,
+    the updated vbPrevMatched as an [n1][2] array)."""
+    L = lib()
+    L.orc_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
+                                                C.c_float, C.c_float, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    o1 = np.ascontiguousarray(octave_1, np.int32)
+    a1 = np.ascontiguousarray(angle_1, np.float32)
+    d1 = np.ascontiguousarray(desc_1, np.uint8)
+    pm = np.array(prev_matched, np.float32).reshape(-1, 2).copy()
+    xy2 = np.ascontiguousarray(xy_2, np.float32).reshape(-1, 2)
+    o2 = np.ascontiguousarray(octave_2, np.int32)
+    a2 = np.ascontiguousarray(angle_2, np.float32)
+    d2 = np.ascontiguousarray(desc_2, np.uint8)
+    cs = np.ascontiguousarray(cell_start_2, np.int32)
+    ci = np.ascontiguousarray(cell_idx_2, np.int32)
+    n1, n2 = len(o1), len(o2)
+    assert len(pm) == n1 and len(cs) == 64 * 48 + 1
+    match = np.full(max(n1, 1), -1, np.int32)
+    n = L.orc_search_for_initialization(_ptr(o1), _ptr(a1), _ptr(d1), n1, _ptr(pm), _ptr(xy2), _ptr(o2), _ptr(a2), _ptr(d2), n2,
+                                        _ptr(cs), _ptr(ci), min_x, min_y, inv_w, inv_h, int(window_size), nn_ratio,
+                                        int(check_orientation), _ptr(match))
+    return n, match[:n1], pm
+
+
 class Vocabulary:
     """A DBoW2 vocabulary tree in the oracle (TemplatedVocabulary, reference
     Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h).  Arrays are per node, entry 0 = root."""
