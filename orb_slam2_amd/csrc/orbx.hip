@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -39,6 +41,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // small static arrays.  The limit is a property of the kernel on a device, shared by every context,
 // so it is set to this one value and never to a context's own need.
 constexpr int kMaxDynamicLds = 160 * 1024 - 256;
+constexpr int kPipeSlots = 3;  // pinned upload slots and pinned result slots of the pipelined host batch path
 
 // Scratch of the entry point that allocates nothing (orbx_stereo_match_batch_device_noalloc): a
 // fixed array in the code object, one copy per GPU.  Host code reaches it only through the address
@@ -127,11 +130,11 @@ struct orbx_ctx {
     size_t h_stage_bytes = 0;
     // pipelined host batches: two upload slots and two result slots in pinned memory, a stream per
     // copy direction, events chaining upload -> compute -> download per slot
-    void* h_up[2] = {nullptr, nullptr};
-    void* h_res[2] = {nullptr, nullptr};
+    void* h_up[kPipeSlots] = {};
+    void* h_res[kPipeSlots] = {};
     size_t h_up_bytes = 0, h_res_bytes = 0;
     hipStream_t st_up = nullptr, st_down = nullptr;
-    hipEvent_t ev_up[2], ev_done[2], ev_down[2];
+    hipEvent_t ev_up[kPipeSlots], ev_done[kPipeSlots], ev_down[kPipeSlots];
     bool pipe_made = false;
     // auxiliary compute stream (pyramid + blur beside FAST + quadtree) and its ordering events
     hipStream_t st_aux = nullptr;
@@ -771,7 +774,7 @@ int ensure_pipeline(orbx_ctx* c, size_t up_bytes, size_t res_bytes) {
     if (!c->pipe_made) {
         HIP_TRY(c, hipStreamCreateWithFlags(&c->st_up, hipStreamNonBlocking));
         HIP_TRY(c, hipStreamCreateWithFlags(&c->st_down, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < kPipeSlots; ++i) {
             HIP_TRY(c, hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming));
             HIP_TRY(c, hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
             HIP_TRY(c, hipEventCreateWithFlags(&c->ev_down[i], hipEventDisableTiming));
@@ -779,7 +782,7 @@ int ensure_pipeline(orbx_ctx* c, size_t up_bytes, size_t res_bytes) {
         c->pipe_made = true;
     }
     if (up_bytes > c->h_up_bytes) {
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < kPipeSlots; ++i) {
             if (c->h_up[i]) HIP_TRY(c, hipHostFree(c->h_up[i]));
             c->h_up[i] = nullptr;
             HIP_TRY(c, hipHostMalloc(&c->h_up[i], up_bytes, hipHostMallocDefault));
@@ -787,7 +790,7 @@ int ensure_pipeline(orbx_ctx* c, size_t up_bytes, size_t res_bytes) {
         c->h_up_bytes = up_bytes;
     }
     if (res_bytes > c->h_res_bytes) {
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < kPipeSlots; ++i) {
             if (c->h_res[i]) HIP_TRY(c, hipHostFree(c->h_res[i]));
             c->h_res[i] = nullptr;
             HIP_TRY(c, hipHostMalloc(&c->h_res[i], res_bytes, hipHostMallocDefault));
@@ -797,9 +800,32 @@ int ensure_pipeline(orbx_ctx* c, size_t up_bytes, size_t res_bytes) {
     return ORBX_OK;
 }
 
-// Host batch in chunks: while chunk k is extracted on the compute stream, chunk k+1 is staged and
-// uploaded and the results of chunk k-1 are downloaded and handed to the caller.  The device
-// arenas hold the whole batch (pyramids of every frame stay readable afterwards).
+// A counter one thread advances and others wait on; fail() releases every waiter.
+struct Gate {
+    std::mutex m;
+    std::condition_variable cv;
+    int value = -1;
+    bool failed = false;
+    void set(int v) {
+        { std::lock_guard<std::mutex> l(m); value = v; }
+        cv.notify_all();
+    }
+    void fail() {
+        { std::lock_guard<std::mutex> l(m); failed = true; }
+        cv.notify_all();
+    }
+    bool wait_for(int v) {  // false: some stage of the pipeline failed
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return value >= v || failed; });
+        return !failed;
+    }
+};
+
+// Host batch in chunks, three host roles side by side: a staging thread re-pitches chunk k+1 into a
+// pinned upload slot, the calling thread enqueues upload, extraction and download of chunk k, and a
+// delivery thread hands the results of chunk k-1 to the caller -- so neither the link nor the GPU
+// waits for a host copy.  kPipeSlots upload slots and result slots; the device arenas hold the whole
+// batch (pyramids of every frame stay readable afterwards).
 int extract_batch_pipelined(orbx_ctx* c, int n, const uint8_t* const* imgs, int width, int height, const int* strides,
                             orbx_kp* kps, int kp_cap, uint8_t* desc, int* n_out, int cap) {
     const size_t plane = c->plane[0];
@@ -811,66 +837,109 @@ int extract_batch_pipelined(orbx_ctx* c, int n, const uint8_t* const* imgs, int 
     if (rc) return rc;
     if ((rc = sync_ctx(c))) return rc;  // nothing of an earlier call is still in flight
     const int aset = c->arena_set ^ 1;
-    const int host_threads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
-    const int nchunks = (n + m - 1) / m;
+    const int hw = (int)std::max(2u, std::min(12u, std::thread::hardware_concurrency()));
+    const int stage_threads = std::max(1, hw * 2 / 3), deliver_threads = std::max(1, hw - stage_threads);
+    // chunk boundaries.  Short chunks at both ends (less time to fill and drain the pipeline) were measured and
+    // lost: the fixed cost of enqueueing a chunk outweighs them.
+    std::vector<int> first;
+    for (int f = 0; f < n; f += m) first.push_back(f);
+    first.push_back(n);
+    const int nchunks = (int)first.size() - 1;
+    const int device = c->prm.device_id;
     orbx_kp* d_kps = (orbx_kp*)c->d_out_kps.p;
     uint8_t* d_desc = (uint8_t*)c->d_out_desc.p;
     int32_t* d_cnt = (int32_t*)c->d_out_n.p;
 
-    auto consume = [&](int k) -> int {  // results of chunk k: pinned slot -> the caller's arrays
-        const int slot = k & 1, f0 = k * m, mk = std::min(m, n - f0);
-        HIP_TRY(c, hipEventSynchronize(c->ev_down[slot]));
-        const uint8_t* base = (const uint8_t*)c->h_res[slot];
-        const int32_t* cnt = (const int32_t*)(base + res_kps + res_desc);
-        parallel_for(mk, host_threads, [&](int i) {
-            const int kk = std::min(cnt[i], kp_cap);
-            n_out[f0 + i] = kk;
-            if (kk > 0) {
-                std::memcpy(kps + (size_t)(f0 + i) * kp_cap, base + (size_t)i * cap * sizeof(orbx_kp), (size_t)kk * sizeof(orbx_kp));
-                std::memcpy(desc + (size_t)(f0 + i) * kp_cap * 32, base + res_kps + (size_t)i * cap * 32, (size_t)kk * 32);
-            }
-        });
-        return ORBX_OK;
+    Gate staged, uploaded, enqueued, delivered;  // staged: chunk k lies in its slot; uploaded: its copy is enqueued; ...
+    std::atomic<int> worker_rc{ORBX_OK}, worker_hip{0};
+    auto fail_all = [&](int code, int hip) {
+        int expect = ORBX_OK;
+        if (worker_rc.compare_exchange_strong(expect, code)) worker_hip = hip;
+        staged.fail(); uploaded.fail(); enqueued.fail(); delivered.fail();
     };
-
     const bool ptrace = c->dbg_trace;
     auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tp0 = tnow();
-    for (int k = 0; k < nchunks; ++k) {
-        const int slot = k & 1, f0 = k * m, mk = std::min(m, n - f0);
-        if (ptrace) std::fprintf(stderr, "chunk %d start %.3f\n", k, tnow() - tp0);
-        if (k >= 2) HIP_TRY(c, hipEventSynchronize(c->ev_up[slot]));  // upload slot free again
-        if (ptrace) std::fprintf(stderr, "chunk %d slot free %.3f\n", k, tnow() - tp0);
-        uint8_t* up = (uint8_t*)c->h_up[slot];
-        parallel_for(mk, host_threads, [&](int i) {
-            uint8_t* d = up + (size_t)i * plane;
-            const uint8_t* s = imgs[f0 + i];
-            const int st = strides[f0 + i];
-            for (int y = 0; y < height; ++y) std::memcpy(d + (size_t)y * pitch, s + (size_t)y * st, (size_t)width);
-        });
-        HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->d_pyr[aset].p + (size_t)f0 * plane, up, (size_t)mk * plane, hipMemcpyHostToDevice,
-                                  c->st_up));
-        HIP_TRY(c, hipEventRecord(c->ev_up[slot], c->st_up));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_up[slot], 0));
-        // every chunk works in the same arena set (different frames of it) and alternates the retained-point set
-        rc = run_batch(c, mk, nullptr, 0, 0, d_kps + (size_t)f0 * cap, cap, d_desc + (size_t)f0 * cap * 32, d_cnt + f0, aset,
-                       k & 1, n, f0, true);
-        if (rc) return rc;
-        HIP_TRY(c, hipEventRecord(c->ev_done[slot], c->desc_pending[k & 1] ? c->st_desc : c->stream));  // after the descriptors
-        // the result slot of chunk k-2 was consumed before chunk k-1 was enqueued (below)
-        HIP_TRY(c, hipStreamWaitEvent(c->st_down, c->ev_done[slot], 0));
-        uint8_t* res = (uint8_t*)c->h_res[slot];
-        HIP_TRY(c, hipMemcpyAsync(res, d_kps + (size_t)f0 * cap, (size_t)mk * cap * sizeof(orbx_kp), hipMemcpyDeviceToHost,
-                                  c->st_down));
-        HIP_TRY(c, hipMemcpyAsync(res + res_kps, d_desc + (size_t)f0 * cap * 32, (size_t)mk * cap * 32, hipMemcpyDeviceToHost,
-                                  c->st_down));
-        HIP_TRY(c, hipMemcpyAsync(res + res_kps + res_desc, d_cnt + f0, (size_t)mk * 4, hipMemcpyDeviceToHost, c->st_down));
-        HIP_TRY(c, hipEventRecord(c->ev_down[slot], c->st_down));
-        if (ptrace) std::fprintf(stderr, "chunk %d enqueued %.3f\n", k, tnow() - tp0);
-        if (k >= 1 && (rc = consume(k - 1))) return rc;
-        if (ptrace) std::fprintf(stderr, "chunk %d consumed prev %.3f\n", k, tnow() - tp0);
+
+    std::thread stager([&] {
+        if (hipSetDevice(device) != hipSuccess) return fail_all(ORBX_E_HIP, (int)hipGetLastError());
+        for (int k = 0; k < nchunks; ++k) {
+            const int slot = k % kPipeSlots, f0 = first[k], mk = first[k + 1] - f0;
+            if (k >= kPipeSlots) {  // the slot's previous upload has left the pinned buffer
+                if (!uploaded.wait_for(k - kPipeSlots)) return;
+                const hipError_t e = hipEventSynchronize(c->ev_up[slot]);
+                if (e != hipSuccess) return fail_all(ORBX_E_HIP, (int)e);
+            }
+            uint8_t* up = (uint8_t*)c->h_up[slot];
+            parallel_for(mk, stage_threads, [&](int i) {
+                uint8_t* d = up + (size_t)i * plane;
+                const uint8_t* s = imgs[f0 + i];
+                const int st = strides[f0 + i];
+                for (int y = 0; y < height; ++y) std::memcpy(d + (size_t)y * pitch, s + (size_t)y * st, (size_t)width);
+            });
+            if (ptrace) std::fprintf(stderr, "chunk %d staged %.3f\n", k, tnow() - tp0);
+            staged.set(k);
+        }
+    });
+    std::thread deliverer([&] {
+        if (hipSetDevice(device) != hipSuccess) return fail_all(ORBX_E_HIP, (int)hipGetLastError());
+        for (int k = 0; k < nchunks; ++k) {  // results of chunk k: pinned slot -> the caller's arrays
+            const int slot = k % kPipeSlots, f0 = first[k], mk = first[k + 1] - f0;
+            if (!enqueued.wait_for(k)) return;
+            const hipError_t e = hipEventSynchronize(c->ev_down[slot]);
+            if (e != hipSuccess) return fail_all(ORBX_E_HIP, (int)e);
+            const uint8_t* base = (const uint8_t*)c->h_res[slot];
+            const int32_t* cnt = (const int32_t*)(base + res_kps + res_desc);
+            parallel_for(mk, deliver_threads, [&](int i) {
+                const int kk = std::min(cnt[i], kp_cap);
+                n_out[f0 + i] = kk;
+                if (kk > 0) {
+                    std::memcpy(kps + (size_t)(f0 + i) * kp_cap, base + (size_t)i * cap * sizeof(orbx_kp), (size_t)kk * sizeof(orbx_kp));
+                    std::memcpy(desc + (size_t)(f0 + i) * kp_cap * 32, base + res_kps + (size_t)i * cap * 32, (size_t)kk * 32);
+                }
+            });
+            if (ptrace) std::fprintf(stderr, "chunk %d delivered %.3f\n", k, tnow() - tp0);
+            delivered.set(k);
+        }
+    });
+
+    auto enqueue_all = [&]() -> int {
+        for (int k = 0; k < nchunks; ++k) {
+            const int slot = k % kPipeSlots, f0 = first[k], mk = first[k + 1] - f0;
+            if (!staged.wait_for(k)) return ORBX_OK;  // the failing thread left its code in worker_rc
+            HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->d_pyr[aset].p + (size_t)f0 * plane, c->h_up[slot], (size_t)mk * plane,
+                                      hipMemcpyHostToDevice, c->st_up));
+            HIP_TRY(c, hipEventRecord(c->ev_up[slot], c->st_up));
+            uploaded.set(k);
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_up[slot], 0));
+            // every chunk works in the same arena set (different frames of it) and alternates the retained-point set
+            int rc_ = run_batch(c, mk, nullptr, 0, 0, d_kps + (size_t)f0 * cap, cap, d_desc + (size_t)f0 * cap * 32, d_cnt + f0, aset,
+                                k & 1, n, f0, true);
+            if (rc_) return rc_;
+            HIP_TRY(c, hipEventRecord(c->ev_done[slot], c->desc_pending[k & 1] ? c->st_desc : c->stream));  // after the descriptors
+            if (k >= kPipeSlots && !delivered.wait_for(k - kPipeSlots)) return ORBX_OK;  // the result slot has been handed over
+            HIP_TRY(c, hipStreamWaitEvent(c->st_down, c->ev_done[slot], 0));
+            uint8_t* res = (uint8_t*)c->h_res[slot];
+            HIP_TRY(c, hipMemcpyAsync(res, d_kps + (size_t)f0 * cap, (size_t)mk * cap * sizeof(orbx_kp), hipMemcpyDeviceToHost,
+                                      c->st_down));
+            HIP_TRY(c, hipMemcpyAsync(res + res_kps, d_desc + (size_t)f0 * cap * 32, (size_t)mk * cap * 32, hipMemcpyDeviceToHost,
+                                      c->st_down));
+            HIP_TRY(c, hipMemcpyAsync(res + res_kps + res_desc, d_cnt + f0, (size_t)mk * 4, hipMemcpyDeviceToHost, c->st_down));
+            HIP_TRY(c, hipEventRecord(c->ev_down[slot], c->st_down));
+            if (ptrace) std::fprintf(stderr, "chunk %d enqueued %.3f\n", k, tnow() - tp0);
+            enqueued.set(k);
+        }
+        return ORBX_OK;
+    };
+    rc = enqueue_all();
+    if (rc) fail_all(rc, c->last_hip);
+    stager.join();
+    deliverer.join();
+    if (worker_rc.load() != ORBX_OK) {
+        c->last_hip = worker_hip.load();
+        sync_ctx(c);  // leave nothing in flight that still names the pinned slots
+        return worker_rc.load();
     }
-    if ((rc = consume(nchunks - 1))) return rc;
     { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     fill_batch(c, n, nullptr, 0, 0, n, 0, aset);  // read-backs and the stereo stage see the whole batch
     c->last_kps = d_kps;
@@ -1073,7 +1142,7 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
                       &c->d_st_sad, &c->d_st_u, &c->d_st_depth};
     for (DevBuf* b : bufs) release(b);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kPipeSlots; ++i) {
         if (c->h_up[i]) (void)hipHostFree(c->h_up[i]);
         if (c->h_res[i]) (void)hipHostFree(c->h_res[i]);
     }
@@ -1092,7 +1161,7 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
         (void)hipStreamDestroy(c->st_aux);
     }
     if (c->pipe_made) {
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < kPipeSlots; ++i) {
             (void)hipEventDestroy(c->ev_up[i]);
             (void)hipEventDestroy(c->ev_done[i]);
             (void)hipEventDestroy(c->ev_down[i]);
