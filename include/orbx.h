@@ -357,6 +357,27 @@ int orbx_search_by_bow_keyframes_batch_device(orbx_ctx* ctx, int n, const uint32
                                               const orbx_kp* d_kps_2, const uint8_t* d_valid_2, int kp_cap_2, float nn_ratio,
                                               int check_orientation, int32_t* d_match12, int32_t* d_nmatches, int sync);
 
+/* Replaces ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (reference
+ * src/ORBmatcher.cc:686-852 with CheckDistEpipolarLine, :140-157; called from LocalMapping::CreateNewMapPoints,
+ * src/LocalMapping.cc:329) for a batch of keyframe pairs: between the features that hold no map point yet
+ * (d_has_mp_* == 0), node by node of the FeatureVectors, every feature of the first keyframe takes the candidate
+ * of smallest descriptor distance <= 50 (TH_LOW; the last of equals) that is far enough from the epipole (when
+ * neither feature has a stereo measurement: d_u_right_* < 0 or null) and within 3.84 * mvLevelSigma2 of the
+ * epipolar line of F12; a feature of the second keyframe may serve several of the first, as in the reference,
+ * which never sets vbMatched2.  d_kps_un_*: mvKeysUn; d_f12[f*9 ..]: F12 row-major as ComputeF12 returns it
+ * (src/LocalMapping.cc:624); d_epipole[f*2 ..]: (ex, ey) of :693-699; scale factors and level sigmas are the
+ * context's.  Outputs: d_match12[f*kp_cap_1 + i] = the second keyframe's feature (-1: none), so that
+ * vMatchedPairs is every (i, d_match12[i] >= 0) in index order (:841-849); d_nmatches[f] = the return value.
+ * kp_cap_1, kp_cap_2 <= 16384; descriptors 16-byte aligned. */
+int orbx_search_for_triangulation_batch_device(orbx_ctx* ctx, int n, const uint32_t* d_fv_node_1, const uint32_t* d_fv_idx_1,
+                                               const int32_t* d_fv_n_1, const uint8_t* d_desc_1, const orbx_kp* d_kps_un_1,
+                                               const uint8_t* d_has_mp_1, const float* d_u_right_1, int kp_cap_1,
+                                               const uint32_t* d_fv_node_2, const uint32_t* d_fv_idx_2, const int32_t* d_fv_n_2,
+                                               const uint8_t* d_desc_2, const orbx_kp* d_kps_un_2, const uint8_t* d_has_mp_2,
+                                               const float* d_u_right_2, int kp_cap_2, const float* d_f12,
+                                               const float* d_epipole, int only_stereo, int check_orientation,
+                                               int32_t* d_match12, int32_t* d_nmatches, int sync);
+
 /* ---- descriptor consumer: the matcher of the monocular initialisation ----------------------
  * Replaces ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, vector<cv::Point2f>& vbPrevMatched,
  * vector<int>& vnMatches12, int windowSize) (reference src/ORBmatcher.cc:418-549; called from

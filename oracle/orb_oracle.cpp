@@ -1781,3 +1781,105 @@ extern "C" int orc_search_for_initialization(const int32_t* octave1, const float
         }
     return nmatches;
 }
+
+// ORBmatcher::CheckDistEpipolarLine (reference src/ORBmatcher.cc:140-157): the squared distance of kp2 from the
+// epipolar line x1' F12 against 3.84 * mvLevelSigma2[kp2.octave] (a double product).  f12: row-major 3x3.
+static bool check_dist_epipolar_line(float x1, float y1, float x2, float y2, const float* f12, float sigma2) {
+    const float a = x1 * f12[0] + y1 * f12[3] + f12[6];
+    const float b = x1 * f12[1] + y1 * f12[4] + f12[7];
+    const float c = x1 * f12[2] + y1 * f12[5] + f12[8];
+    const float num = a * x2 + b * y2 + c;
+    const float den = a * a + b * b;
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * sigma2;
+}
+
+// ORBmatcher::SearchForTriangulation (reference src/ORBmatcher.cc:686-852), the matcher of
+// LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:329): between the features of two keyframes that hold no map
+// point yet, node by node of the FeatureVectors, the smallest descriptor distance <= TH_LOW among the candidates that
+// lie far enough from the epipole (monocular pairs) and close enough to the epipolar line.  The reference never sets
+// vbMatched2 (:706 is its only write), so a feature of the second keyframe may serve several of the first.
+// kps*_xy: mvKeysUn positions; has_mp*: GetMapPoint(idx) != NULL; u_right*: mvuRight; f12: row-major; (ex, ey): the
+// epipole in the second image (:693-699, computed by the caller).  match12 = vMatches12, from which vMatchedPairs is
+// every (i, match12[i]) with match12[i] >= 0 in index order (:841-849); returns nmatches.
+extern "C" int orc_search_for_triangulation(const uint32_t* fv_node_1, const uint32_t* fv_idx_1, int fv_n_1,
+                                            const uint8_t* desc_1, const float* kps1_xy, const float* angle_1,
+                                            const uint8_t* has_mp_1, const float* u_right_1, int n_1,
+                                            const uint32_t* fv_node_2, const uint32_t* fv_idx_2, int fv_n_2,
+                                            const uint8_t* desc_2, const float* kps2_xy, const float* angle_2,
+                                            const int32_t* octave_2, const uint8_t* has_mp_2, const float* u_right_2,
+                                            int n_2, const float* f12, float ex, float ey, const float* scale_factors,
+                                            const float* level_sigma2, int only_stereo, int check_orientation,
+                                            int32_t* match12) {
+    (void)n_2;
+    const int HISTO_LENGTH = 30, TH_LOW = 50;
+    int nmatches = 0;                                  // :705
+    for (int i = 0; i < n_1; i++) match12[i] = -1;     // :707
+    std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+    const float factor = 1.0f / HISTO_LENGTH;          // :713
+    int a = 0, b = 0;
+    while (a < fv_n_1 && b < fv_n_2) {  // :720
+        const uint32_t node_1 = fv_node_1[a], node_2 = fv_node_2[b];
+        if (node_1 == node_2) {
+            int a_end = a, b_end = b;
+            while (a_end < fv_n_1 && fv_node_1[a_end] == node_1) a_end++;
+            while (b_end < fv_n_2 && fv_node_2[b_end] == node_2) b_end++;
+            for (int i1 = a; i1 < a_end; i1++) {  // :724
+                const unsigned idx1 = fv_idx_1[i1];
+                if (has_mp_1[idx1]) continue;  // :728-732
+                const bool bStereo1 = u_right_1[idx1] >= 0;  // :734
+                if (only_stereo && !bStereo1) continue;      // :736-738
+                const uint8_t* d1 = desc_1 + (size_t)idx1 * 32;
+                int bestDist = TH_LOW, bestIdx2 = -1;  // :744-745
+                for (int i2 = b; i2 < b_end; i2++) {
+                    const unsigned idx2 = fv_idx_2[i2];
+                    if (has_mp_2[idx2]) continue;  // :751-755 (vbMatched2 stays false)
+                    const bool bStereo2 = u_right_2[idx2] >= 0;  // :757
+                    if (only_stereo && !bStereo2) continue;      // :759-761
+                    const int dist = orc_descriptor_distance(d1, desc_2 + (size_t)idx2 * 32);
+                    if (dist > TH_LOW || dist > bestDist) continue;  // :767
+                    const float x2 = kps2_xy[2 * idx2], y2 = kps2_xy[2 * idx2 + 1];
+                    if (!bStereo1 && !bStereo2) {  // :772-778
+                        const float distex = ex - x2, distey = ey - y2;
+                        if (distex * distex + distey * distey < 100 * scale_factors[octave_2[idx2]]) continue;
+                    }
+                    if (check_dist_epipolar_line(kps1_xy[2 * idx1], kps1_xy[2 * idx1 + 1], x2, y2, f12,
+                                                 level_sigma2[octave_2[idx2]])) {  // :780-784
+                        bestIdx2 = (int)idx2;
+                        bestDist = dist;
+                    }
+                }
+                if (bestIdx2 >= 0) {  // :787-804
+                    match12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (check_orientation) {
+                        float rot = angle_1[idx1] - angle_2[bestIdx2];
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)std::round(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        rotHist[bin].push_back((int)idx1);
+                    }
+                }
+            }
+            a = a_end;  // :807-808
+            b = b_end;
+        } else if (node_1 < node_2) {  // :810-813
+            while (a < fv_n_1 && fv_node_1[a] < node_2) a++;
+        } else {  // :814-817
+            while (b < fv_n_2 && fv_node_2[b] < node_1) b++;
+        }
+    }
+    if (check_orientation) {  // :820-839
+        int ind1 = -1, ind2 = -1, ind3 = -1, size[30];
+        for (int i = 0; i < HISTO_LENGTH; i++) size[i] = (int)rotHist[i].size();
+        three_maxima(size, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (size_t j = 0; j < rotHist[i].size(); j++) {
+                    match12[rotHist[i][j]] = -1;
+                    nmatches--;
+                }
+    }
+    return nmatches;
+}

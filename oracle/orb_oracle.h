@@ -290,6 +290,15 @@ int orc_search_for_initialization(const int32_t* octave1, const float* angle1, c
                                   float min_x, float min_y, float inv_w, float inv_h, int window_size, float nn_ratio,
                                   int check_orientation, int32_t* match12);
 
+/* ORBmatcher::SearchForTriangulation (reference src/ORBmatcher.cc:686-852, CheckDistEpipolarLine :140-157). */
+int orc_search_for_triangulation(const uint32_t* fv_node_1, const uint32_t* fv_idx_1, int fv_n_1, const uint8_t* desc_1,
+                                 const float* kps1_xy, const float* angle_1, const uint8_t* has_mp_1, const float* u_right_1,
+                                 int n_1, const uint32_t* fv_node_2, const uint32_t* fv_idx_2, int fv_n_2, const uint8_t* desc_2,
+                                 const float* kps2_xy, const float* angle_2, const int32_t* octave_2, const uint8_t* has_mp_2,
+                                 const float* u_right_2, int n_2, const float* f12, float ex, float ey,
+                                 const float* scale_factors, const float* level_sigma2, int only_stereo,
+                                 int check_orientation, int32_t* match12);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,7 +56,7 @@ EXPORTS = [
     "orbx_search_by_projection_batch_device", "orbx_set_debug_flag",
     "orbx_stereo_match_batch_device_noalloc", "orbx_search_local_map_batch_device", "orbx_search_by_bow_batch_device",
     "orbx_search_by_bow_keyframes_batch_device", "orbx_rgbd_depth_batch_device",
-    "orbx_search_for_initialization_batch_device",
+    "orbx_search_for_initialization_batch_device", "orbx_search_for_triangulation_batch_device",
 ]
 
 _lib = None
@@ -105,6 +105,8 @@ def load_library():
                                                             i32, vp, vp, i32]
     L.orbx_search_for_initialization_batch_device.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, f32, f32, f32,
                                                               f32, i32, f32, i32, vp, vp, i32]
+    L.orbx_search_for_triangulation_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp,
+                                                             i32, vp, vp, i32, i32, vp, vp, i32]
     L.orbx_gray_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, i32, i32, vp, i32, C.c_size_t, i32]
     L.orbx_remap_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, vp, vp, i32, vp, i32, i32, i32,
                                           C.c_size_t, i32]
@@ -409,6 +411,20 @@ class ORBextractor:
             self._ctx, n, C.c_void_p(d_fv_node_1), C.c_void_p(d_fv_idx_1), C.c_void_p(d_fv_n_1), C.c_void_p(d_desc_1),
             C.c_void_p(d_kps_1), C.c_void_p(d_valid_1), kp_cap_1, C.c_void_p(d_fv_node_2), C.c_void_p(d_fv_idx_2),
             C.c_void_p(d_fv_n_2), C.c_void_p(d_desc_2), C.c_void_p(d_kps_2), C.c_void_p(d_valid_2), kp_cap_2, nn_ratio,
+            int(check_orientation), C.c_void_p(d_match12), C.c_void_p(d_nmatches), int(sync)), self._ctx)
+
+    def search_for_triangulation_batch_device(self, n, d_fv_node_1, d_fv_idx_1, d_fv_n_1, d_desc_1, d_kps_un_1, d_has_mp_1,
+                                              d_u_right_1, kp_cap_1, d_fv_node_2, d_fv_idx_2, d_fv_n_2, d_desc_2, d_kps_un_2,
+                                              d_has_mp_2, d_u_right_2, kp_cap_2, d_f12, d_epipole, only_stereo,
+                                              check_orientation, d_match12, d_nmatches, sync=True):
+        """ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (src/ORBmatcher.cc:686-852) for a
+        batch of keyframe pairs; d_u_right_* may be 0 (no stereo measurements).  See
+        orbx_search_for_triangulation_batch_device."""
+        _check(self._L.orbx_search_for_triangulation_batch_device(
+            self._ctx, n, C.c_void_p(d_fv_node_1), C.c_void_p(d_fv_idx_1), C.c_void_p(d_fv_n_1), C.c_void_p(d_desc_1),
+            C.c_void_p(d_kps_un_1), C.c_void_p(d_has_mp_1), C.c_void_p(d_u_right_1), kp_cap_1, C.c_void_p(d_fv_node_2),
+            C.c_void_p(d_fv_idx_2), C.c_void_p(d_fv_n_2), C.c_void_p(d_desc_2), C.c_void_p(d_kps_un_2), C.c_void_p(d_has_mp_2),
+            C.c_void_p(d_u_right_2), kp_cap_2, C.c_void_p(d_f12), C.c_void_p(d_epipole), int(only_stereo),
             int(check_orientation), C.c_void_p(d_match12), C.c_void_p(d_nmatches), int(sync)), self._ctx)
 
     def search_for_initialization_batch_device(self, n, d_kps_un_1, d_desc_1, d_n_1, kp_cap_1, d_prev_matched, d_kps_un_2,

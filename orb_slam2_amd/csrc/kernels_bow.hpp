@@ -442,6 +442,33 @@ __device__ __forceinline__ int proj_rot_bin(float last_angle, float cur_angle) {
     return min(max(bin, 0), kHistoLength - 1);  // angles outside [0, 360) would leave the table in the reference
 }
 
+// ComputeThreeMaxima (ORBmatcher.cc:1638-1679) over bin sizes: the bins that stay, -1 where fewer than three do.
+__device__ __forceinline__ void rot_three_maxima(const int* hist, int* keep) {
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int i = 0; i < kHistoLength; ++i) {
+        const int s = hist[i];
+        if (s > max1) {
+            max3 = max2; max2 = max1; max1 = s;
+            ind3 = ind2; ind2 = ind1; ind1 = i;
+        } else if (s > max2) {
+            max3 = max2; max2 = s;
+            ind3 = ind2; ind2 = i;
+        } else if (s > max3) {
+            max3 = s;
+            ind3 = i;
+        }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
+        ind2 = -1;
+        ind3 = -1;
+    } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
+        ind3 = -1;
+    }
+    keep[0] = ind1;
+    keep[1] = ind2;
+    keep[2] = ind3;
+}
+
 // The best cached candidate of a listed point that no earlier point holds (-1: none); a holder also
 // marks every such candidate as still wanted by it.
 __device__ __forceinline__ int proj_cached_choice(uint32_t ent, const uint2* cache, const int32_t* n_cache, const int32_t* held,
@@ -632,31 +659,7 @@ __global__ __launch_bounds__(kProjThreads) void k_search_projection(ProjDev D) {
     }
     __syncthreads();
     if (P.check_orientation) {
-        if (tid == 0) {  // ComputeThreeMaxima (:1638-1679)
-            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-            for (int i = 0; i < kHistoLength; ++i) {
-                const int s = s_hist[i];
-                if (s > max1) {
-                    max3 = max2; max2 = max1; max1 = s;
-                    ind3 = ind2; ind2 = ind1; ind1 = i;
-                } else if (s > max2) {
-                    max3 = max2; max2 = s;
-                    ind3 = ind2; ind2 = i;
-                } else if (s > max3) {
-                    max3 = s;
-                    ind3 = i;
-                }
-            }
-            if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
-                ind2 = -1;
-                ind3 = -1;
-            } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
-                ind3 = -1;
-            }
-            s_keep[0] = ind1;
-            s_keep[1] = ind2;
-            s_keep[2] = ind3;
-        }
+        if (tid == 0) rot_three_maxima(s_hist, s_keep);
         __syncthreads();
         for (int q = tid; q < nq; q += kProjThreads) {
             const int v = qm[q];

@@ -186,31 +186,7 @@ __global__ __launch_bounds__(kBowMatchThreads) void k_search_bow(BowMatchDev D) 
         }
     }
     __syncthreads();
-    if (D.check_orientation && tid == 0) {  // ComputeThreeMaxima (:1638-1679)
-        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-        for (int i = 0; i < kHistoLength; ++i) {
-            const int s = s_hist[i];
-            if (s > max1) {
-                max3 = max2; max2 = max1; max1 = s;
-                ind3 = ind2; ind2 = ind1; ind1 = i;
-            } else if (s > max2) {
-                max3 = max2; max2 = s;
-                ind3 = ind2; ind2 = i;
-            } else if (s > max3) {
-                max3 = s;
-                ind3 = i;
-            }
-        }
-        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
-            ind2 = -1;
-            ind3 = -1;
-        } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
-            ind3 = -1;
-        }
-        s_keep[0] = ind1;
-        s_keep[1] = ind2;
-        s_keep[2] = ind3;
-    }
+    if (D.check_orientation && tid == 0) rot_three_maxima(s_hist, s_keep);
     __syncthreads();
     for (int i = tid; i < cap_out; i += kBowMatchThreads) {
         const int m = __hip_atomic_load(&match[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -224,6 +200,143 @@ __global__ __launch_bounds__(kBowMatchThreads) void k_search_bow(BowMatchDev D) 
         }
     }
     __syncthreads();
+    if (tid == 0) D.n_matches[f] = s_nm;
+}
+
+// ---- ORBmatcher::SearchForTriangulation (reference src/ORBmatcher.cc:686-852, CheckDistEpipolarLine :140-157) ----
+// The matcher of LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:329): between the features of two keyframes
+// that hold no map point yet, node by node, the smallest descriptor distance <= TH_LOW among the candidates far
+// enough from the epipole (when neither feature has a stereo measurement) and close enough to the epipolar line.
+// The reference never marks a feature of the second keyframe as matched (vbMatched2 is only initialised, :706), so
+// every feature of the first keyframe decides on its own: "dist > bestDist -> continue" with bestDist lowered only
+// by accepted candidates leaves the accepted candidate of smallest distance, the LAST of equals in list order.
+struct TriDev {
+    const uint32_t *fv_node_1, *fv_idx_1;
+    const int32_t* fv_n_1;
+    const uint8_t* desc_1;
+    const orbx_kp* kps_1;      // mvKeysUn
+    const uint8_t* has_mp_1;   // GetMapPoint(idx) != NULL
+    const float* u_right_1;    // mvuRight, null: no feature has a stereo measurement
+    int cap_1;
+    const uint32_t *fv_node_2, *fv_idx_2;
+    const int32_t* fv_n_2;
+    const uint8_t* desc_2;
+    const orbx_kp* kps_2;
+    const uint8_t* has_mp_2;
+    const float* u_right_2;
+    int cap_2;
+    const float* f12;          // [n][9], row-major
+    const float* epipole;      // [n][2]: (ex, ey) in the second image (:693-699)
+    float scale[ORBX_MAX_LEVELS], sigma2[ORBX_MAX_LEVELS];  // pKF2->mvScaleFactors, mvLevelSigma2
+    int only_stereo, check_orientation;
+    int32_t* match12;          // [n][cap_1]
+    int32_t* n_matches;        // [n]
+};
+
+// grid = pairs, block = 1024: 64 groups of sixteen lanes, a group per feature of the first keyframe's FeatureVector.
+__global__ __launch_bounds__(kBowMatchThreads) void k_search_triangulation(TriDev D) {
+    __shared__ int s_hist[kHistoLength], s_keep[3], s_nm;
+    const int f = blockIdx.x, tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
+    const int cap_1 = D.cap_1, cap_2 = D.cap_2;
+    const int n1 = max(0, min(D.fv_n_1[f], cap_1)), n2 = max(0, min(D.fv_n_2[f], cap_2));
+    const uint32_t* node1 = D.fv_node_1 + (size_t)f * cap_1;
+    const uint32_t* idx1s = D.fv_idx_1 + (size_t)f * cap_1;
+    const uint32_t* node2 = D.fv_node_2 + (size_t)f * cap_2;
+    const uint32_t* idx2s = D.fv_idx_2 + (size_t)f * cap_2;
+    const orbx_kp* kps1 = D.kps_1 + (size_t)f * cap_1;
+    const orbx_kp* kps2 = D.kps_2 + (size_t)f * cap_2;
+    const uint8_t* mp1 = D.has_mp_1 + (size_t)f * cap_1;
+    const uint8_t* mp2 = D.has_mp_2 + (size_t)f * cap_2;
+    const float* ur1 = D.u_right_1 ? D.u_right_1 + (size_t)f * cap_1 : nullptr;
+    const float* ur2 = D.u_right_2 ? D.u_right_2 + (size_t)f * cap_2 : nullptr;
+    int32_t* match12 = D.match12 + (size_t)f * cap_1;
+    float F[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) F[i] = D.f12[(size_t)f * 9 + i];
+    const float ex = D.epipole[(size_t)f * 2], ey = D.epipole[(size_t)f * 2 + 1];
+    for (int i = tid; i < cap_1; i += kBowMatchThreads) match12[i] = -1;  // :707
+    if (tid < kHistoLength) s_hist[tid] = 0;
+    if (tid == 0) s_nm = 0;
+    __syncthreads();
+
+    for (int e = grp; e < n1; e += kBowMatchThreads / 16) {
+        const uint32_t node = node1[e];
+        const int i1 = (int)idx1s[e];
+        if (mp1[i1]) continue;  // :728-732; the sixteen lanes of a group decide alike
+        const bool stereo1 = ur1 && ur1[i1] >= 0.0f;  // :734
+        if (D.only_stereo && !stereo1) continue;      // :736-738
+        // the second keyframe's run of this node: [lo, hi)
+        int lo = 0, hi = n2;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (node2[mid] < node) lo = mid + 1; else hi = mid;
+        }
+        int up = lo, top = n2;
+        while (up < top) {
+            const int mid = (up + top) >> 1;
+            if (node2[mid] <= node) up = mid + 1; else top = mid;
+        }
+        const orbx_kp k1 = kps1[i1];
+        // epipolar line in the second image, l = x1' F12 = [a b c] (:142-145)
+        const float a = __fadd_rn(__fadd_rn(__fmul_rn(k1.x, F[0]), __fmul_rn(k1.y, F[3])), F[6]);
+        const float b = __fadd_rn(__fadd_rn(__fmul_rn(k1.x, F[1]), __fmul_rn(k1.y, F[4])), F[7]);
+        const float c = __fadd_rn(__fadd_rn(__fmul_rn(k1.x, F[2]), __fmul_rn(k1.y, F[5])), F[8]);
+        const float den = __fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b));
+        const uint4 d0 = *reinterpret_cast<const uint4*>(D.desc_1 + ((size_t)f * cap_1 + i1) * 32);
+        const uint4 d1 = *reinterpret_cast<const uint4*>(D.desc_1 + ((size_t)f * cap_1 + i1) * 32 + 16);
+        uint32_t key = 0xFFFFFFFFu;  // distance << 16 | (0xFFFF - list position): smallest distance, last of equals
+        int best = -1;
+        for (int j = lo + sub; j < up; j += 16) {
+            const int i2 = (int)idx2s[j];
+            if (mp2[i2]) continue;  // :751-755
+            const bool stereo2 = ur2 && ur2[i2] >= 0.0f;  // :757
+            if (D.only_stereo && !stereo2) continue;      // :759-761
+            const uint4* dp = reinterpret_cast<const uint4*>(D.desc_2 + ((size_t)f * cap_2 + i2) * 32);
+            const uint4 da = dp[0], db = dp[1];
+            const uint32_t dist = __popc(d0.x ^ da.x) + __popc(d0.y ^ da.y) + __popc(d0.z ^ da.z) + __popc(d0.w ^ da.w) +
+                                  __popc(d1.x ^ db.x) + __popc(d1.y ^ db.y) + __popc(d1.z ^ db.z) + __popc(d1.w ^ db.w);
+            if (dist > (uint32_t)kThLow) continue;  // :767
+            const orbx_kp k2 = kps2[i2];
+            const int level2 = min(max(k2.octave, 0), ORBX_MAX_LEVELS - 1);
+            if (!stereo1 && !stereo2) {  // :772-778
+                const float distex = __fsub_rn(ex, k2.x), distey = __fsub_rn(ey, k2.y);
+                if (__fadd_rn(__fmul_rn(distex, distex), __fmul_rn(distey, distey)) < __fmul_rn(100.0f, D.scale[level2])) continue;
+            }
+            if (den == 0.0f) continue;  // :151-152
+            const float num = __fadd_rn(__fadd_rn(__fmul_rn(a, k2.x), __fmul_rn(b, k2.y)), c);
+            const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+            if (!((double)dsqr < 3.84 * (double)D.sigma2[level2])) continue;  // :156
+            const uint32_t kc = (dist << 16) | (uint32_t)(0xFFFF - (j - lo));
+            if (kc < key) {
+                key = kc;
+                best = i2;
+            }
+        }
+        window_min_dpp<0xB1>(key, best);
+        window_min_dpp<0x4E>(key, best);
+        window_min_dpp<0x141>(key, best);
+        window_min_dpp<0x140>(key, best);
+        if (sub == 0 && key != 0xFFFFFFFFu) {  // :787-804
+            match12[i1] = best;
+            atomicAdd(&s_nm, 1);
+            if (D.check_orientation) atomicAdd(&s_hist[proj_rot_bin(k1.angle, kps2[best].angle)], 1);
+        }
+    }
+    __syncthreads();
+    if (D.check_orientation) {  // :820-839
+        if (tid == 0) rot_three_maxima(s_hist, s_keep);
+        __syncthreads();
+        for (int i = tid; i < cap_1; i += kBowMatchThreads) {
+            const int m = __hip_atomic_load(&match12[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (m < 0) continue;
+            const int bin = proj_rot_bin(kps1[i].angle, kps2[m].angle);
+            if (bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) {
+                match12[i] = -1;
+                atomicSub(&s_nm, 1);
+            }
+        }
+        __syncthreads();
+    }
     if (tid == 0) D.n_matches[f] = s_nm;
 }
 

@@ -39,33 +39,6 @@ inline size_t init_match_lds_bytes(int cap_1, int cap_2, int list_cap) {
     return (size_t)kInitGroups * list_cap * 8 + (size_t)cap_2 * 4 + (size_t)cap_1 * 4;
 }
 
-// ComputeThreeMaxima (ORBmatcher.cc:1638-1679) over bin sizes: the bins that stay, -1 where fewer than three do.
-__device__ __forceinline__ void init_three_maxima(const int* hist, int* keep) {
-    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-    for (int i = 0; i < kHistoLength; ++i) {
-        const int s = hist[i];
-        if (s > max1) {
-            max3 = max2; max2 = max1; max1 = s;
-            ind3 = ind2; ind2 = ind1; ind1 = i;
-        } else if (s > max2) {
-            max3 = max2; max2 = s;
-            ind3 = ind2; ind2 = i;
-        } else if (s > max3) {
-            max3 = s;
-            ind3 = i;
-        }
-    }
-    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
-        ind2 = -1;
-        ind3 = -1;
-    } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
-        ind3 = -1;
-    }
-    keep[0] = ind1;
-    keep[1] = ind2;
-    keep[2] = ind3;
-}
-
 // grid = pairs of frames, block = 1024, dynamic LDS = init_match_lds_bytes(cap_1, cap_2, list_cap).
 __global__ __launch_bounds__(kInitThreads) void k_search_init(InitDev D) {
     __shared__ int s_cnt[kInitGroups], s_hist[kHistoLength], s_keep[3], s_nm, s_wave[kInitThreads / 64];
@@ -192,7 +165,7 @@ __global__ __launch_bounds__(kInitThreads) void k_search_init(InitDev D) {
     }
 
     if (D.check_orientation) {  // :515-540
-        if (tid == 0) init_three_maxima(s_hist, s_keep);
+        if (tid == 0) rot_three_maxima(s_hist, s_keep);
         __syncthreads();
     }
     for (int i1 = tid; i1 < cap_1; i1 += kInitThreads) {

@@ -1703,6 +1703,52 @@ extern "C" int orbx_search_by_bow_keyframes_batch_device(orbx_ctx* c, int n, con
                          sync);
 }
 
+extern "C" int orbx_search_for_triangulation_batch_device(
+    orbx_ctx* c, int n, const uint32_t* d_fv_node_1, const uint32_t* d_fv_idx_1, const int32_t* d_fv_n_1, const uint8_t* d_desc_1,
+    const orbx_kp* d_kps_un_1, const uint8_t* d_has_mp_1, const float* d_u_right_1, int kp_cap_1, const uint32_t* d_fv_node_2,
+    const uint32_t* d_fv_idx_2, const int32_t* d_fv_n_2, const uint8_t* d_desc_2, const orbx_kp* d_kps_un_2,
+    const uint8_t* d_has_mp_2, const float* d_u_right_2, int kp_cap_2, const float* d_f12, const float* d_epipole,
+    int only_stereo, int check_orientation, int32_t* d_match12, int32_t* d_nmatches, int sync) {
+    if (!c || !d_fv_node_1 || !d_fv_idx_1 || !d_fv_n_1 || !d_desc_1 || !d_kps_un_1 || !d_has_mp_1 || !d_fv_node_2 ||
+        !d_fv_idx_2 || !d_fv_n_2 || !d_desc_2 || !d_kps_un_2 || !d_has_mp_2 || !d_f12 || !d_epipole || !d_match12 ||
+        !d_nmatches || n < 1 || kp_cap_1 < 1 || kp_cap_2 < 1 || ((uintptr_t)d_desc_1 | (uintptr_t)d_desc_2) % 16)
+        return ORBX_E_INVALID;
+    if (kp_cap_1 > 16384 || kp_cap_2 > 16384) return ORBX_E_CAPACITY;  // as the bag-of-words transform
+    HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    { int rc_ = join(c); if (rc_) return rc_; }
+    TriDev D;
+    D.fv_node_1 = d_fv_node_1;
+    D.fv_idx_1 = d_fv_idx_1;
+    D.fv_n_1 = d_fv_n_1;
+    D.desc_1 = d_desc_1;
+    D.kps_1 = d_kps_un_1;
+    D.has_mp_1 = d_has_mp_1;
+    D.u_right_1 = d_u_right_1;
+    D.cap_1 = kp_cap_1;
+    D.fv_node_2 = d_fv_node_2;
+    D.fv_idx_2 = d_fv_idx_2;
+    D.fv_n_2 = d_fv_n_2;
+    D.desc_2 = d_desc_2;
+    D.kps_2 = d_kps_un_2;
+    D.has_mp_2 = d_has_mp_2;
+    D.u_right_2 = d_u_right_2;
+    D.cap_2 = kp_cap_2;
+    D.f12 = d_f12;
+    D.epipole = d_epipole;
+    for (int i = 0; i < ORBX_MAX_LEVELS; ++i) {
+        D.scale[i] = c->tab.scale[std::min(i, c->prm.nlevels - 1)];
+        D.sigma2[i] = c->tab.sigma2[std::min(i, c->prm.nlevels - 1)];
+    }
+    D.only_stereo = only_stereo ? 1 : 0;
+    D.check_orientation = check_orientation ? 1 : 0;
+    D.match12 = d_match12;
+    D.n_matches = d_nmatches;
+    hipLaunchKernelGGL(k_search_triangulation, dim3(n), dim3(kBowMatchThreads), 0, c->stream, D);
+    HIP_TRY(c, hipGetLastError());
+    if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
+    return ORBX_OK;
+}
+
 extern "C" int orbx_search_for_initialization_batch_device(orbx_ctx* c, int n, const orbx_kp* d_kps_un_1,
                                                            const uint8_t* d_desc_1, const int32_t* d_n_1, int kp_cap_1,
                                                            float* d_prev_matched, const orbx_kp* d_kps_un_2,

@@ -448,6 +448,33 @@ def search_by_bow_keyframes(fv_node_1, fv_idx_1, desc_1, angle_1, valid_1, fv_no
     return n, match[:n_1]
 
 
+def search_for_triangulation(side_1, side_2, f12, epipole, scale_factors, level_sigma2, only_stereo, check_orientation):
+    """ORBmatcher::SearchForTriangulation (reference src/ORBmatcher.cc:686-852).  side_k = (fv_node, fv_idx, desc, xy, angle,
+    octave, has_mp, u_right) of keyframe k (u_right None: all -1); returns (nmatches, vMatches12)."""
+    L = lib()
+    vp = C.c_void_p
+    L.orc_search_for_triangulation.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp,
+                                               vp, C.c_int, vp, C.c_float, C.c_float, vp, vp, C.c_int, C.c_int, vp]
+
+    def prep(side):
+        node, idx, desc, xy, angle, octave, has_mp, u_right = side
+        n = len(angle)
+        ur = np.full(n, -1.0, np.float32) if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        return (np.ascontiguousarray(node, np.uint32), np.ascontiguousarray(idx, np.uint32), np.ascontiguousarray(desc, np.uint8),
+                np.ascontiguousarray(xy, np.float32).reshape(-1, 2), np.ascontiguousarray(angle, np.float32),
+                np.ascontiguousarray(octave, np.int32), np.ascontiguousarray(has_mp, np.uint8), ur, n)
+    a, b = prep(side_1), prep(side_2)
+    F = np.ascontiguousarray(f12, np.float32).reshape(9)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    s2 = np.ascontiguousarray(level_sigma2, np.float32)
+    match = np.full(max(a[8], 1), -1, np.int32)
+    n = L.orc_search_for_triangulation(_ptr(a[0]), _ptr(a[1]), len(a[0]), _ptr(a[2]), _ptr(a[3]), _ptr(a[4]), _ptr(a[6]), _ptr(a[7]),
+                                       a[8], _ptr(b[0]), _ptr(b[1]), len(b[0]), _ptr(b[2]), _ptr(b[3]), _ptr(b[4]), _ptr(b[5]),
+                                       _ptr(b[6]), _ptr(b[7]), b[8], _ptr(F), float(epipole[0]), float(epipole[1]), _ptr(sf),
+                                       _ptr(s2), int(only_stereo), int(check_orientation), _ptr(match))
+    return n, match[:a[8]]
+
+
 def search_for_initialization(octave_1, angle_1, desc_1, prev_matched, xy_2, octave_2, angle_2, desc_2, cell_start_2,
                               cell_idx_2, min_x, min_y, inv_w, inv_h, window_size, nn_ratio, check_orientation):
     """ORBmatcher::SearchForInitialization (reference src/ORBmatcher.cc:418-549); returns (nmatches, vnMatches12,

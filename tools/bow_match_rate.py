@@ -81,6 +81,27 @@ def main():
     print("SearchByBoW: %.3f ms per %d pairs (%.0f features, %.0f matches per pair)"
           % (ms, n, float(d_n.float().mean()), float(nm.float().mean())))
 
+    # SearchForTriangulation on the same pairs: no feature holds a map point, no stereo measurements, the views
+    # differ by a shift along x (epipolar lines = rows, up to the one-row offset between consecutive views)
+    no_mp = torch.zeros((n, cap), dtype=torch.uint8, device="cuda")
+    f12 = torch.tensor([[0, 0, 0], [0, 0, -1], [0, 1, 0]], dtype=torch.float32, device="cuda").repeat(n, 1, 1).contiguous()
+    epipole = torch.tensor([[-1e5, 188.0]], dtype=torch.float32, device="cuda").repeat(n, 1).contiguous()
+
+    def triangulation():
+        ex.search_for_triangulation_batch_device(n, fnode.data_ptr(), fidx.data_ptr(), fn.data_ptr(), d_desc.data_ptr(),
+                                                 d_kps.data_ptr(), no_mp.data_ptr(), 0, cap, fnode_f.data_ptr(), fidx_f.data_ptr(),
+                                                 fn_f.data_ptr(), desc_f.data_ptr(), kps_f.data_ptr(), no_mp.data_ptr(), 0, cap,
+                                                 f12.data_ptr(), epipole.data_ptr(), 0, 1, match.data_ptr(), nm.data_ptr(),
+                                                 sync=False)
+    triangulation()
+    ex.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        triangulation()
+    ex.synchronize()
+    ms = (time.perf_counter() - t0) * 100.0
+    print("SearchForTriangulation: %.3f ms per %d pairs (%.0f matches per pair)" % (ms, n, float(nm.float().mean())))
+
 
 if __name__ == "__main__":
     main()
