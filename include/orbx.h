@@ -259,6 +259,22 @@ int orbx_search_window_batch_device(orbx_ctx* ctx, int n, const orbx_kp* d_kps_u
                                     const int32_t* d_nq, int32_t* d_best_idx, int32_t* d_best_dist, int sync);
 
 
+/* Replaces the search inside ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, th) (reference
+ * src/ORBmatcher.cc:929-986; KeyFrame::GetFeaturesInArea, src/KeyFrame.cc:575-614; called from
+ * LocalMapping::SearchInNeighbors, src/LocalMapping.cc:573 and :601) for a batch of keyframes: query i of keyframe f
+ * is a map point that passed the tests of :873-922, with u, v (:892-893), ur (:899), radius (:927) and
+ * min_level = nPredictedLevel - 1, max_level = nPredictedLevel (:948).  Among the keyframe's keypoints in the
+ * window and on those levels whose reprojection error passes the chi-square test of :951-975 (5.99, or 7.8 with
+ * d_u_right[idx] >= 0; d_u_right may be null; mvInvLevelSigma2 is the context's), d_best_idx receives the one of
+ * smallest descriptor distance, first in grid order (-1: none), d_best_dist that distance (256: none).  The
+ * caller applies bestDist <= TH_LOW and the map updates of :989-1008 in query order.  The second overload,
+ * Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (:1014-1137), and both directions of SearchBySim3 (:1139-1363)
+ * search without the chi-square test: they are orbx_search_window_batch_device with d_u_right = d_taken = null. */
+int orbx_fuse_search_batch_device(orbx_ctx* ctx, int n, const orbx_kp* d_kps_un, int kp_cap, const int32_t* d_cell_start,
+                                  const int32_t* d_cell_idx, const uint8_t* d_desc, const float* d_u_right, float min_x,
+                                  float min_y, float inv_w, float inv_h, const orbx_window_query* d_queries, int q_cap,
+                                  const int32_t* d_nq, int32_t* d_best_idx, int32_t* d_best_dist, int sync);
+
 /* ---- descriptor consumer: ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) ----
  * Replaces the whole function (reference src/ORBmatcher.cc:1365-1507, ComputeThreeMaxima
  * :1638-1679) for a batch of (current frame, last frame) pairs: the last frame's map points are

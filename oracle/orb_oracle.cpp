@@ -1883,3 +1883,57 @@ extern "C" int orc_search_for_triangulation(const uint32_t* fv_node_1, const uin
     }
     return nmatches;
 }
+
+// The search of ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) for one map point that passed the tests
+// of :873-922 (reference src/ORBmatcher.cc:929-986; KeyFrame::GetFeaturesInArea, src/KeyFrame.cc:575-614): u, v
+// (:892-893), ur (:899), radius (:927), nPredictedLevel (:924).  u_right: pKF->mvuRight (null: all -1);
+// inv_level_sigma2: pKF->mvInvLevelSigma2.  Returns bestIdx (-1: none) and bestDist (256: none); the caller applies
+// bestDist <= TH_LOW (:989).
+extern "C" int orc_fuse_search(const float* kps_xy, const int32_t* octave, const uint8_t* desc, const float* u_right,
+                               const int32_t* cell_start, const int32_t* cell_idx, float min_x, float min_y, float inv_w,
+                               float inv_h, float u, float v, float ur, float radius, int nPredictedLevel,
+                               const float* inv_level_sigma2, const uint8_t q_desc[32], int* best_dist) {
+    int bestDist = 256, bestIdx = -1;  // :938-939
+    *best_dist = bestDist;
+    const int COLS = 64, ROWS = 48;
+    const float x = u, y = v, r = radius;
+    const int nMinCellX = std::max(0, (int)std::floor((x - min_x - r) * inv_w));  // KeyFrame.cc:580
+    if (nMinCellX >= COLS) return -1;
+    const int nMaxCellX = std::min(COLS - 1, (int)std::ceil((x - min_x + r) * inv_w));
+    if (nMaxCellX < 0) return -1;
+    const int nMinCellY = std::max(0, (int)std::floor((y - min_y - r) * inv_h));
+    if (nMinCellY >= ROWS) return -1;
+    const int nMaxCellY = std::min(ROWS - 1, (int)std::ceil((y - min_y + r) * inv_h));
+    if (nMaxCellY < 0) return -1;
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const int c = ix * ROWS + iy;
+            for (int j = cell_start[c]; j < cell_start[c + 1]; j++) {
+                const int idx = cell_idx[j];
+                const float kpx = kps_xy[2 * idx], kpy = kps_xy[2 * idx + 1];
+                if (!(std::fabs(kpx - x) < r && std::fabs(kpy - y) < r)) continue;  // KeyFrame.cc:604-608
+                const int kpLevel = octave[idx];
+                if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;  // :948
+                if (u_right && u_right[idx] >= 0) {  // :951-964
+                    const float kpr = u_right[idx];
+                    const float ex = u - kpx;
+                    const float ey = v - kpy;
+                    const float er = ur - kpr;
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;
+                } else {  // :965-975
+                    const float ex = u - kpx;
+                    const float ey = v - kpy;
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+                }
+                const int dist = orc_descriptor_distance(q_desc, desc + (size_t)idx * 32);
+                if (dist < bestDist) {  // :981-985
+                    bestDist = dist;
+                    bestIdx = idx;
+                }
+            }
+        }
+    *best_dist = bestDist;
+    return bestIdx;
+}

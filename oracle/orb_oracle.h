@@ -299,6 +299,13 @@ int orc_search_for_triangulation(const uint32_t* fv_node_1, const uint32_t* fv_i
                                  const float* scale_factors, const float* level_sigma2, int only_stereo,
                                  int check_orientation, int32_t* match12);
 
+/* The search of ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) for one projected map point (reference
+ * src/ORBmatcher.cc:929-986). */
+int orc_fuse_search(const float* kps_xy, const int32_t* octave, const uint8_t* desc, const float* u_right,
+                    const int32_t* cell_start, const int32_t* cell_idx, float min_x, float min_y, float inv_w, float inv_h,
+                    float u, float v, float ur, float radius, int nPredictedLevel, const float* inv_level_sigma2,
+                    const uint8_t q_desc[32], int* best_dist);
+
 #ifdef __cplusplus
 }
 #endif

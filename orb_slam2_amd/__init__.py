@@ -57,6 +57,7 @@ EXPORTS = [
     "orbx_stereo_match_batch_device_noalloc", "orbx_search_local_map_batch_device", "orbx_search_by_bow_batch_device",
     "orbx_search_by_bow_keyframes_batch_device", "orbx_rgbd_depth_batch_device",
     "orbx_search_for_initialization_batch_device", "orbx_search_for_triangulation_batch_device",
+    "orbx_fuse_search_batch_device",
 ]
 
 _lib = None
@@ -107,6 +108,7 @@ def load_library():
                                                               f32, i32, f32, i32, vp, vp, i32]
     L.orbx_search_for_triangulation_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp,
                                                              i32, vp, vp, i32, i32, vp, vp, i32]
+    L.orbx_fuse_search_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, f32, f32, f32, f32, vp, i32, vp, vp, vp, i32]
     L.orbx_gray_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, i32, i32, vp, i32, C.c_size_t, i32]
     L.orbx_remap_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, vp, vp, i32, vp, i32, i32, i32,
                                           C.c_size_t, i32]
@@ -412,6 +414,15 @@ class ORBextractor:
             C.c_void_p(d_kps_1), C.c_void_p(d_valid_1), kp_cap_1, C.c_void_p(d_fv_node_2), C.c_void_p(d_fv_idx_2),
             C.c_void_p(d_fv_n_2), C.c_void_p(d_desc_2), C.c_void_p(d_kps_2), C.c_void_p(d_valid_2), kp_cap_2, nn_ratio,
             int(check_orientation), C.c_void_p(d_match12), C.c_void_p(d_nmatches), int(sync)), self._ctx)
+
+    def fuse_search_batch_device(self, n, d_kps_un, kp_cap, d_cell_start, d_cell_idx, d_desc, d_u_right, min_x, min_y, inv_w,
+                                 inv_h, d_queries, q_cap, d_nq, d_best_idx, d_best_dist, sync=True):
+        """The search of ORBmatcher::Fuse(pKF, vpMapPoints, th) (src/ORBmatcher.cc:929-986) for a batch of keyframes and
+        their projected map points (WINDOW_QUERY_DTYPE records); see orbx_fuse_search_batch_device."""
+        _check(self._L.orbx_fuse_search_batch_device(
+            self._ctx, n, C.c_void_p(d_kps_un), kp_cap, C.c_void_p(d_cell_start), C.c_void_p(d_cell_idx), C.c_void_p(d_desc),
+            C.c_void_p(d_u_right), min_x, min_y, inv_w, inv_h, C.c_void_p(d_queries), q_cap, C.c_void_p(d_nq),
+            C.c_void_p(d_best_idx), C.c_void_p(d_best_dist), int(sync)), self._ctx)
 
     def search_for_triangulation_batch_device(self, n, d_fv_node_1, d_fv_idx_1, d_fv_n_1, d_desc_1, d_kps_un_1, d_has_mp_1,
                                               d_u_right_1, kp_cap_1, d_fv_node_2, d_fv_idx_2, d_fv_n_2, d_desc_2, d_kps_un_2,

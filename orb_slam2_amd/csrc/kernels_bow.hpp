@@ -263,7 +263,8 @@ struct WindowDev {
 // the same amount of work whatever the cells hold.  The first strict minimum in visiting order is
 // the minimum of (distance, entry number).  All sixteen lanes of a group call this together; each
 // receives the winner (-1: none) and its key (distance in bits 23..31, 0xFFFFFFFF: none).
-// held(i2) tells whether feature i2 holds a map point the query must respect;
+// held(i2, keypoint) tells whether the query must pass over feature i2 (it holds a map point the query respects,
+// or it fails a test of the caller's);
 // on_cand(i2, dist, key, keypoint) runs for every candidate that passes the filters.
 template <int CTRL>
 __device__ __forceinline__ void window_min_dpp(uint32_t& k, int& v) {
@@ -324,7 +325,7 @@ __device__ __forceinline__ void window_best(const WindowDev& W, int f, float x, 
                     const orbx_kp kp = kps[i2];
                     bool ok = !check_levels || (kp.octave >= minLevel && (maxLevel < 0 || kp.octave <= maxLevel));
                     ok = ok && fabsf(__fsub_rn(kp.x, x)) < r && fabsf(__fsub_rn(kp.y, y)) < r;  // :389
-                    ok = ok && !held(i2);                                                       // ORBmatcher.cc:1440-1442
+                    ok = ok && !held(i2, kp);                                                     // ORBmatcher.cc:1440-1442
                     if (ok && W.u_right) {
                         const float urf = W.u_right[(size_t)f * W.kp_cap + i2];
                         if (urf > 0 && fabsf(__fsub_rn(ur, urf)) > r) ok = false;  // :1444-1450
@@ -372,7 +373,52 @@ __global__ __launch_bounds__(256) void k_search_window(WindowDev W, const Window
     uint32_t kmin;
     const uint8_t* taken = W.taken ? W.taken + (size_t)f * W.kp_cap : nullptr;
     window_best(W, f, Q->u, Q->v, Q->radius, Q->ur, Q->min_level, Q->max_level, d0, d1, sub,
-                [&](int i2) { return taken && taken[i2]; }, [](int, uint32_t, uint32_t, const orbx_kp&) {}, &win, &kmin);
+                [&](int i2, const orbx_kp&) { return taken && taken[i2]; }, [](int, uint32_t, uint32_t, const orbx_kp&) {}, &win, &kmin);
+    if (sub == 0) {
+        const size_t o = (size_t)f * W.q_cap + q;
+        best_idx[o] = win;
+        best_dist[o] = kmin == 0xFFFFFFFFu ? 256 : (int)(kmin >> 23);
+    }
+}
+
+// ---- the search of ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) --------------------
+// (reference src/ORBmatcher.cc:929-986 with KeyFrame::GetFeaturesInArea, src/KeyFrame.cc:575-614): a projected map
+// point looks for the most similar keypoint of the keyframe in its window, on the predicted level or the one
+// below (the query's level range), among the keypoints whose reprojection error passes the chi-square test --
+// (ex^2 + ey^2) * mvInvLevelSigma2[level] <= 5.99, with a stereo measurement (ex^2 + ey^2 + er^2) * ... <= 7.8.
+// The searches of different map points do not depend on each other; what the reference does with the result
+// (replace / add an observation, :989-1008) changes the map, not the search, and stays with the caller.
+struct FuseGate {
+    const float* u_right;                  // [n][kp_cap] (mvuRight) or null: no keypoint has a stereo measurement
+    float inv_sigma2[ORBX_MAX_LEVELS];     // mvInvLevelSigma2
+};
+
+// grid = (ceil(q_cap / 16), keyframes), block = 256.  W.u_right and W.taken are null.
+__global__ __launch_bounds__(256) void k_fuse_search(WindowDev W, FuseGate G, const WindowQuery* __restrict__ queries,
+                                                     const int32_t* __restrict__ n_q, int32_t* __restrict__ best_idx,
+                                                     int32_t* __restrict__ best_dist) {
+    const int f = blockIdx.y, sub = threadIdx.x & 15;
+    const int q = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (q >= min(n_q[f], W.q_cap)) return;  // whole groups leave together
+    const WindowQuery* Q = queries + (size_t)f * W.q_cap + q;
+    const uint4 d0 = *reinterpret_cast<const uint4_unaligned*>(Q->desc), d1 = *reinterpret_cast<const uint4_unaligned*>(Q->desc + 16);
+    const float u = Q->u, v = Q->v, ur = Q->ur;
+    const float* u_right = G.u_right ? G.u_right + (size_t)f * W.kp_cap : nullptr;
+    int win;
+    uint32_t kmin;
+    window_best(W, f, u, v, Q->radius, ur, Q->min_level, Q->max_level, d0, d1, sub,
+                [&](int i2, const orbx_kp& kp) {
+                    const float inv = G.inv_sigma2[min(max(kp.octave, 0), ORBX_MAX_LEVELS - 1)];
+                    const float ex = __fsub_rn(u, kp.x), ey = __fsub_rn(v, kp.y);
+                    const float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+                    const float kpr = u_right ? u_right[i2] : -1.0f;
+                    if (kpr >= 0.0f) {  // :951-964
+                        const float er = __fsub_rn(ur, kpr);
+                        return (double)__fmul_rn(__fadd_rn(e2, __fmul_rn(er, er)), inv) > 7.8;
+                    }
+                    return (double)__fmul_rn(e2, inv) > 5.99;  // :965-975
+                },
+                [](int, uint32_t, uint32_t, const orbx_kp&) {}, &win, &kmin);
     if (sub == 0) {
         const size_t o = (size_t)f * W.q_cap + q;
         best_idx[o] = win;
@@ -578,7 +624,7 @@ __global__ __launch_bounds__(kProjThreads) void k_search_projection(ProjDev D) {
                     const bool holds = m->flags & 1;
                     int win;
                     uint32_t key;
-                    window_best(D.W, f, u, v, radius, ur, lo, hi, d0, d1, sub, [&](int i2) { return held[i2] < q; },
+                    window_best(D.W, f, u, v, radius, ur, lo, hi, d0, d1, sub, [&](int i2, const orbx_kp&) { return held[i2] < q; },
                                 [&](int i2, uint32_t dist, uint32_t kc, const orbx_kp&) {
                                     if (dist > (uint32_t)kThHigh) return;
                                     if (holds) atomicMin(&minq[i2], q);
@@ -801,7 +847,7 @@ __global__ __launch_bounds__(kProjThreads) void k_search_local(LocalDev D) {
                 int win;
                 uint32_t key;
                 window_best(D.W, f, m->u, m->v, radius, m->ur, m->level - 1, m->level, d0, d1, sub,
-                            [&](int i2) { return held[i2] < q; },
+                            [&](int i2, const orbx_kp&) { return held[i2] < q; },
                             [&](int i2, uint32_t dist, uint32_t kc, const orbx_kp& kp) {
                                 if (holds && dist <= (uint32_t)kThHigh) atomicMin(&minq[i2], q);
                                 top2_merge(k1, k2, v1, v2, kc, 0xFFFFFFFFu, i2 | (kp.octave << 20), -1);

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kInitThreads) void k_search_init(InitDev D) {
         __syncthreads();
     }
 
-    const auto nobody = [](int) { return false; };
+    const auto nobody = [](int, const orbx_kp&) { return false; };
     for (int c0 = 0; c0 < n0; c0 += kInitGroups) {
         // ---- all windows of the chunk at once: lists of (key, feature), key = distance << 23 | visiting order ----
         if (sub == 0) s_cnt[grp] = 0;

@@ -1548,6 +1548,27 @@ extern "C" int orbx_search_window_batch_device(orbx_ctx* c, int n, const orbx_kp
     return ORBX_OK;
 }
 
+extern "C" int orbx_fuse_search_batch_device(orbx_ctx* c, int n, const orbx_kp* d_kps_un, int kp_cap,
+                                             const int32_t* d_cell_start, const int32_t* d_cell_idx, const uint8_t* d_desc,
+                                             const float* d_u_right, float min_x, float min_y, float inv_w, float inv_h,
+                                             const orbx_window_query* d_queries, int q_cap, const int32_t* d_nq,
+                                             int32_t* d_best_idx, int32_t* d_best_dist, int sync) {
+    if (!c || !d_kps_un || !d_cell_start || !d_cell_idx || !d_desc || !d_queries || !d_nq || !d_best_idx || !d_best_dist ||
+        n < 1 || kp_cap < 1 || q_cap < 1)
+        return ORBX_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    { int rc_ = join(c); if (rc_) return rc_; }
+    WindowDev W = {d_kps_un, d_cell_start, d_cell_idx, d_desc, nullptr, nullptr, min_x, min_y, inv_w, inv_h, kp_cap, q_cap};
+    FuseGate G;
+    G.u_right = d_u_right;
+    for (int i = 0; i < ORBX_MAX_LEVELS; ++i) G.inv_sigma2[i] = c->tab.inv_sigma2[std::min(i, c->prm.nlevels - 1)];
+    hipLaunchKernelGGL(k_fuse_search, dim3((q_cap + 15) / 16, n), dim3(256), 0, c->stream, W, G,
+                       reinterpret_cast<const WindowQuery*>(d_queries), d_nq, d_best_idx, d_best_dist);
+    HIP_TRY(c, hipGetLastError());
+    if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
+    return ORBX_OK;
+}
+
 extern "C" int orbx_search_by_projection_batch_device(orbx_ctx* c, int n, const orbx_kp* d_kps_un, int kp_cap,
                                                       const int32_t* d_cell_start, const int32_t* d_cell_idx,
                                                       const uint8_t* d_desc, const float* d_u_right, const uint8_t* d_taken,

@@ -448,6 +448,28 @@ def search_by_bow_keyframes(fv_node_1, fv_idx_1, desc_1, angle_1, valid_1, fv_no
     return n, match[:n_1]
 
 
+def fuse_search(xy, octave, desc, u_right, cell_start, cell_idx, min_x, min_y, inv_w, inv_h, u, v, ur, radius, level,
+                inv_level_sigma2, q_desc):
+    """The search of ORBmatcher::Fuse(pKF, vpMapPoints, th) for one projected map point (reference src/ORBmatcher.cc:929-986);
+    returns (bestIdx, bestDist)."""
+    L = lib()
+    vp = C.c_void_p
+    L.orc_fuse_search.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                  C.c_float, C.c_float, C.c_int, vp, vp, C.POINTER(C.c_int)]
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    octave = np.ascontiguousarray(octave, np.int32)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    ur_arr = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    cs = np.ascontiguousarray(cell_start, np.int32)
+    ci = np.ascontiguousarray(cell_idx, np.int32)
+    s2 = np.ascontiguousarray(inv_level_sigma2, np.float32)
+    qd = np.ascontiguousarray(q_desc, np.uint8)
+    best = C.c_int(0)
+    idx = L.orc_fuse_search(_ptr(xy), _ptr(octave), _ptr(desc), None if ur_arr is None else _ptr(ur_arr), _ptr(cs), _ptr(ci),
+                            min_x, min_y, inv_w, inv_h, u, v, ur, radius, int(level), _ptr(s2), _ptr(qd), C.byref(best))
+    return idx, best.value
+
+
 def search_for_triangulation(side_1, side_2, f12, epipole, scale_factors, level_sigma2, only_stereo, check_orientation):
     """ORBmatcher::SearchForTriangulation (reference src/ORBmatcher.cc:686-852).  side_k = (fv_node, fv_idx, desc, xy, angle,
     octave, has_mp, u_right) of keyframe k (u_right None: all -1); returns (nmatches, vMatches12)."""
