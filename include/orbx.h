@@ -340,6 +340,33 @@ int orbx_search_local_map_batch_device(orbx_ctx* ctx, int n, const orbx_kp* d_kp
                                        const orbx_local_query* d_queries, int q_cap, const int32_t* d_nq,
                                        int32_t* d_match, int32_t* d_query_match, int32_t* d_nmatches, int sync);
 
+/* Replaces the matching loops of ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th,
+ * ORBdist) (reference src/ORBmatcher.cc:1509-1636; Tracking::Relocalization, src/Tracking.cc:1654 and :1670) and of
+ * ORBmatcher::SearchByProjection(KeyFrame* pKF, Scw, vpPoints, vpMatched, th) (:290-403; LoopClosing::ComputeSim3,
+ * src/LoopClosing.cc:378) for a batch of frames / keyframes.  The caller projects the map points (:1534-1563, :321-360: pose,
+ * image bounds, distance invariance, viewing angle, PredictScale) and passes one record per point, in the reference's
+ * order, with flags bit 1 set for a point the reference skips and bit 0 set otherwise.  Each point searches its
+ * window on levels predicted - 1 .. predicted + level_up (1 for the first function, 0 for the second) among the
+ * features that hold no map point -- d_taken before the call (mvpMapPoints[i] / vpMatched[i] != NULL), and those an
+ * earlier point of this call took -- and takes the most similar one when its distance is <= max_dist (ORBdist;
+ * TH_LOW = 50 for the second function).  check_orientation applies the rotation histogram of :1597-1633 with the
+ * angle in the record against the feature's.  The result is that of the reference's sequential loop.  Outputs as
+ * orbx_search_local_map_batch_device: d_match[f*kp_cap + k] = the point feature k receives (-1: none),
+ * d_query_match[f*q_cap + i] = the feature point i was written to (-1: none), d_nmatches[f] = the return value. */
+typedef struct orbx_guided_query {
+    float u, v;        /* the projection */
+    float angle;       /* pKF->mvKeysUn[i].angle of the map point's keypoint (rotation check only) */
+    int32_t level;     /* nPredictedLevel */
+    float radius;      /* th * mvScaleFactors[nPredictedLevel] */
+    int32_t flags;     /* bit 0: set (the point holds what it takes); bit 1: skip */
+    uint8_t desc[32];  /* MapPoint::GetDescriptor */
+} orbx_guided_query; /* 56 bytes */
+int orbx_search_guided_batch_device(orbx_ctx* ctx, int n, const orbx_kp* d_kps_un, int kp_cap, const int32_t* d_cell_start,
+                                    const int32_t* d_cell_idx, const uint8_t* d_desc, const uint8_t* d_taken, float min_x,
+                                    float min_y, float inv_w, float inv_h, const orbx_guided_query* d_queries, int q_cap,
+                                    const int32_t* d_nq, int level_up, int max_dist, int check_orientation, int32_t* d_match,
+                                    int32_t* d_query_match, int32_t* d_nmatches, int sync);
+
 /* ---- descriptor consumer: matching by vocabulary node -------------------------------------
  * Replaces ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches) (reference
  * src/ORBmatcher.cc:159-290; called from Tracking::TrackReferenceKeyFrame, src/Tracking.cc:894, and

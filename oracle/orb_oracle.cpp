@@ -1937,3 +1937,61 @@ extern "C" int orc_fuse_search(const float* kps_xy, const int32_t* octave, const
     *best_dist = bestDist;
     return bestIdx;
 }
+
+// The matching loops of ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (reference
+// src/ORBmatcher.cc:1565-1632: level_up = 1, max_dist = ORBdist, rotation histogram) and of
+// ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (:362-398: level_up = 0, max_dist = TH_LOW,
+// no histogram) on map points the caller has projected (:1534-1563, :321-360).  q: orc_local_query records read as
+// (u, v, angle, predicted level, radius, flags, descriptor); flags bit 1: the reference skips the point.  taken0:
+// features that hold a map point before the call (:1578, :375).  match[k] = the point feature k receives,
+// query_match[i] = the feature of point i; returns nmatches.
+extern "C" int orc_search_guided(const float* kps_xy, const int32_t* octave, const float* angle, const uint8_t* desc, int n_kp,
+                                 const uint8_t* taken0, const int32_t* cell_start, const int32_t* cell_idx, float min_x,
+                                 float min_y, float inv_w, float inv_h, const orc_local_query* q, int n_q, int level_up,
+                                 int max_dist, int check_orientation, int32_t* match, int32_t* query_match) {
+    const int HISTO_LENGTH = 30;
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<uint8_t> blocked((size_t)std::max(n_kp, 1), 0);
+    for (int k = 0; k < n_kp; k++) {
+        match[k] = -1;
+        blocked[k] = taken0 ? taken0[k] : 0;
+    }
+    std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+    int nmatches = 0;
+    for (int i = 0; i < n_q; i++) {
+        query_match[i] = -1;
+        if (q[i].flags & 2) continue;
+        const int nPredictedLevel = q[i].level;
+        const float radius = q[i].view_cos;  // the record's fifth field: th * mvScaleFactors[nPredictedLevel]
+        int bestDist = 256;
+        const int bestIdx2 = orc_search_window(kps_xy, octave, desc, nullptr, blocked.data(), cell_start, cell_idx, min_x, min_y,
+                                               inv_w, inv_h, q[i].u, q[i].v, radius, nPredictedLevel - 1,
+                                               nPredictedLevel + level_up, 0.0f, q[i].desc, &bestDist);
+        if (bestIdx2 >= 0 && bestDist <= max_dist) {  // :1592, :394
+            match[bestIdx2] = i;
+            query_match[i] = bestIdx2;
+            blocked[bestIdx2] = 1;
+            nmatches++;
+            if (check_orientation) {  // :1597-1607; the record's third field: pKF->mvKeysUn[i].angle
+                float rot = q[i].ur - angle[bestIdx2];
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (check_orientation) {  // :1614-1633
+        int ind1 = -1, ind2 = -1, ind3 = -1, size[30];
+        for (int i = 0; i < HISTO_LENGTH; i++) size[i] = (int)rotHist[i].size();
+        three_maxima(size, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (size_t j = 0; j < rotHist[i].size(); j++) {
+                    query_match[match[rotHist[i][j]]] = -1;
+                    match[rotHist[i][j]] = -1;
+                    nmatches--;
+                }
+    }
+    return nmatches;
+}

@@ -306,6 +306,14 @@ int orc_fuse_search(const float* kps_xy, const int32_t* octave, const uint8_t* d
                     float u, float v, float ur, float radius, int nPredictedLevel, const float* inv_level_sigma2,
                     const uint8_t q_desc[32], int* best_dist);
 
+/* The matching loops of ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (reference
+ * src/ORBmatcher.cc:1565-1632) and SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (:362-398) on projected
+ * map points; the records are read as (u, v, angle, predicted level, radius, flags, descriptor). */
+int orc_search_guided(const float* kps_xy, const int32_t* octave, const float* angle, const uint8_t* desc, int n_kp,
+                      const uint8_t* taken0, const int32_t* cell_start, const int32_t* cell_idx, float min_x, float min_y,
+                      float inv_w, float inv_h, const orc_local_query* q, int n_q, int level_up, int max_dist,
+                      int check_orientation, int32_t* match, int32_t* query_match);
+
 #ifdef __cplusplus
 }
 #endif

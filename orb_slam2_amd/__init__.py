@@ -57,7 +57,7 @@ EXPORTS = [
     "orbx_stereo_match_batch_device_noalloc", "orbx_search_local_map_batch_device", "orbx_search_by_bow_batch_device",
     "orbx_search_by_bow_keyframes_batch_device", "orbx_rgbd_depth_batch_device",
     "orbx_search_for_initialization_batch_device", "orbx_search_for_triangulation_batch_device",
-    "orbx_fuse_search_batch_device",
+    "orbx_fuse_search_batch_device", "orbx_search_guided_batch_device",
 ]
 
 _lib = None
@@ -109,6 +109,8 @@ def load_library():
     L.orbx_search_for_triangulation_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp,
                                                              i32, vp, vp, i32, i32, vp, vp, i32]
     L.orbx_fuse_search_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, f32, f32, f32, f32, vp, i32, vp, vp, vp, i32]
+    L.orbx_search_guided_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, f32, f32, f32, f32, vp, i32, vp, i32, i32, i32,
+                                                  vp, vp, vp, i32]
     L.orbx_gray_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, i32, i32, vp, i32, C.c_size_t, i32]
     L.orbx_remap_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, vp, vp, i32, vp, i32, i32, i32,
                                           C.c_size_t, i32]
@@ -415,6 +417,18 @@ class ORBextractor:
             C.c_void_p(d_fv_n_2), C.c_void_p(d_desc_2), C.c_void_p(d_kps_2), C.c_void_p(d_valid_2), kp_cap_2, nn_ratio,
             int(check_orientation), C.c_void_p(d_match12), C.c_void_p(d_nmatches), int(sync)), self._ctx)
 
+    def search_guided_batch_device(self, n, d_kps_un, kp_cap, d_cell_start, d_cell_idx, d_desc, d_taken, min_x, min_y, inv_w, inv_h,
+                                   d_queries, q_cap, d_nq, level_up, max_dist, check_orientation, d_match, d_query_match,
+                                   d_nmatches, sync=True):
+        """The matching loops of ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist)
+        (src/ORBmatcher.cc:1509-1636; level_up 1) and SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (:290-403; level_up 0,
+        max_dist 50) on projected map points (GUIDED_QUERY_DTYPE records); see orbx_search_guided_batch_device."""
+        _check(self._L.orbx_search_guided_batch_device(
+            self._ctx, n, C.c_void_p(d_kps_un), kp_cap, C.c_void_p(d_cell_start), C.c_void_p(d_cell_idx), C.c_void_p(d_desc),
+            C.c_void_p(d_taken), min_x, min_y, inv_w, inv_h, C.c_void_p(d_queries), q_cap, C.c_void_p(d_nq), int(level_up),
+            int(max_dist), int(check_orientation), C.c_void_p(d_match), C.c_void_p(d_query_match), C.c_void_p(d_nmatches),
+            int(sync)), self._ctx)
+
     def fuse_search_batch_device(self, n, d_kps_un, kp_cap, d_cell_start, d_cell_idx, d_desc, d_u_right, min_x, min_y, inv_w,
                                  inv_h, d_queries, q_cap, d_nq, d_best_idx, d_best_dist, sync=True):
         """The search of ORBmatcher::Fuse(pKF, vpMapPoints, th) (src/ORBmatcher.cc:929-986) for a batch of keyframes and
@@ -523,6 +537,9 @@ class ORBextractor:
         return {self._L.orbx_stage_name(i).decode(): float(ms[i]) for i in range(NUM_STAGES)}
 
 
+GUIDED_QUERY_DTYPE = np.dtype([("u", np.float32), ("v", np.float32), ("angle", np.float32), ("level", np.int32),
+                               ("radius", np.float32), ("flags", np.int32), ("desc", np.uint8, (32,))])
+assert GUIDED_QUERY_DTYPE.itemsize == 56
 WINDOW_QUERY_DTYPE = np.dtype([("u", np.float32), ("v", np.float32), ("radius", np.float32), ("min_level", np.int32),
                                ("max_level", np.int32), ("ur", np.float32), ("desc", np.uint8, (32,))])
 assert WINDOW_QUERY_DTYPE.itemsize == 56

@@ -762,6 +762,8 @@ struct LocalDev {
     int32_t* list;              // scratch [n][2][q_cap]
     int2* pick;                 // scratch [n][q_cap]: (best, second best) feature of an undecided point, -1: none
     int32_t use_lds;            // minq, held and list live in the workgroup's dynamic LDS (2 * kp_cap + 2 * q_cap ints)
+    // the guided searches (k_search_local<true>): accepted distance, levels above the predicted one, rotation check
+    int32_t max_dist, level_up, check_orientation;
 };
 
 // Merges the two smallest keys of another lane into (k1, k2); the values ride along.
@@ -798,9 +800,17 @@ __device__ __forceinline__ void top2_row_merge(uint32_t& k1, uint32_t& k2, int& 
     top2_merge_dpp<0x140>(k1, k2, v1, v2);  // row_mirror
 }
 
+// GUIDED: the same loop-carried dependence without the ratio test, for map points the caller has projected:
+// ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (reference src/ORBmatcher.cc:1509-1636,
+// relocalisation: levels predicted - 1 .. predicted + 1, distance <= ORBdist, rotation histogram) and
+// ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (:290-403, loop closing: levels
+// predicted - 1 .. predicted, distance <= TH_LOW).  Both skip features that hold a map point (:1578, :375) and
+// write theirs at once (:1594, :396), so every point holds what it takes.  The query record is read as
+// (u, v, angle of the map point's keypoint, predicted level, radius, flags, descriptor).
 // grid = frames, block = 1024 (64 groups of sixteen lanes).
+template <bool GUIDED>
 __global__ __launch_bounds__(kProjThreads) void k_search_local(LocalDev D) {
-    __shared__ int s_left, s_nm;
+    __shared__ int s_left, s_nm, s_hist[kHistoLength], s_keep[3];
     const int f = blockIdx.x, tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
     const int kp_cap = D.W.kp_cap, q_cap = D.W.q_cap;
     const int nq = min(D.n_q[f], q_cap);
@@ -838,7 +848,8 @@ __global__ __launch_bounds__(kProjThreads) void k_search_local(LocalDev D) {
                 const int level = min(max(m->level, 0), ORBX_MAX_LEVELS - 1);
                 float r = (double)m->view_cos > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos (:131-137)
                 if (factor) r = __fmul_rn(r, D.th);
-                const float radius = __fmul_rn(r, D.scale[level]);  // :69
+                const float radius = GUIDED ? m->view_cos : __fmul_rn(r, D.scale[level]);  // :69; guided: the caller's (:1563, :360)
+                const uint32_t may_take = GUIDED ? (uint32_t)D.max_dist : (uint32_t)kThHigh;
                 const uint4 d0 = *reinterpret_cast<const uint4_unaligned*>(m->desc);
                 const uint4 d1 = *reinterpret_cast<const uint4_unaligned*>(m->desc + 16);
                 const bool holds = m->flags & 1;
@@ -846,10 +857,10 @@ __global__ __launch_bounds__(kProjThreads) void k_search_local(LocalDev D) {
                 int v1 = -1, v2 = -1;  // feature | octave << 20
                 int win;
                 uint32_t key;
-                window_best(D.W, f, m->u, m->v, radius, m->ur, m->level - 1, m->level, d0, d1, sub,
+                window_best(D.W, f, m->u, m->v, radius, m->ur, m->level - 1, GUIDED ? m->level + D.level_up : m->level, d0, d1, sub,
                             [&](int i2, const orbx_kp&) { return held[i2] < q; },
                             [&](int i2, uint32_t dist, uint32_t kc, const orbx_kp& kp) {
-                                if (holds && dist <= (uint32_t)kThHigh) atomicMin(&minq[i2], q);
+                                if (holds && dist <= may_take) atomicMin(&minq[i2], q);
                                 top2_merge(k1, k2, v1, v2, kc, 0xFFFFFFFFu, i2 | (kp.octave << 20), -1);
                             },
                             &win, &key);
@@ -858,7 +869,9 @@ __global__ __launch_bounds__(kProjThreads) void k_search_local(LocalDev D) {
                 if (k1 != 0xFFFFFFFFu) {
                     const int bestDist = (int)(k1 >> 23), bestLevel = v1 >> 20;
                     const int bestDist2 = k2 == 0xFFFFFFFFu ? 256 : (int)(k2 >> 23), bestLevel2 = k2 == 0xFFFFFFFFu ? -1 : (v2 >> 20);
-                    if (bestDist <= kThHigh) {  // :118
+                    if (GUIDED) {
+                        if (bestDist <= D.max_dist) outcome = best = v1 & 0xFFFFF;  // :1592, :394; the second best plays no part
+                    } else if (bestDist <= kThHigh) {  // :118
                         best = v1 & 0xFFFFF;
                         second = k2 == 0xFFFFFFFFu ? -1 : (v2 & 0xFFFFF);
                         const bool rejected = bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(D.nn_ratio, (float)bestDist2);  // :120
@@ -889,6 +902,24 @@ __global__ __launch_bounds__(kProjThreads) void k_search_local(LocalDev D) {
         __syncthreads();
         n_list = s_left;
         __syncthreads();  // everyone has read s_left before the next round clears it
+    }
+    if (GUIDED && D.check_orientation) {  // :1597-1607, :1614-1633; the record's third float is the keypoint's angle
+        if (tid < kHistoLength) s_hist[tid] = 0;
+        __syncthreads();
+        for (int q = tid; q < nq; q += kProjThreads) {
+            const int v = qm[q];
+            if (v >= 0) atomicAdd(&s_hist[proj_rot_bin(Q[q].ur, D.W.kps_un[(size_t)f * kp_cap + v].angle)], 1);
+        }
+        __syncthreads();
+        if (tid == 0) rot_three_maxima(s_hist, s_keep);
+        __syncthreads();
+        for (int q = tid; q < nq; q += kProjThreads) {
+            const int v = qm[q];
+            if (v < 0) continue;
+            const int bin = proj_rot_bin(Q[q].ur, D.W.kps_un[(size_t)f * kp_cap + v].angle);
+            if (bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) qm[q] = -1;
+        }
+        __syncthreads();
     }
     // a feature ends with the point written last: the holder if there is one (nothing follows it), else the
     // highest index; every write counts (:123-124)

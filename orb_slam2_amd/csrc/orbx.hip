@@ -1649,7 +1649,51 @@ extern "C" int orbx_search_local_map_batch_device(orbx_ctx* c, int n, const orbx
     D.pick = (int2*)c->d_local_pick.p;
     const size_t lds = ((size_t)2 * kp_cap + (size_t)2 * q_cap) * 4;
     D.use_lds = lds <= 64 * 1024 ? 1 : 0;
-    hipLaunchKernelGGL(k_search_local, dim3(n), dim3(kProjThreads), D.use_lds ? lds : 0, c->stream, D);
+    D.max_dist = D.level_up = D.check_orientation = 0;
+    hipLaunchKernelGGL(k_search_local<false>, dim3(n), dim3(kProjThreads), D.use_lds ? lds : 0, c->stream, D);
+    HIP_TRY(c, hipGetLastError());
+    if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_search_guided_batch_device(orbx_ctx* c, int n, const orbx_kp* d_kps_un, int kp_cap,
+                                               const int32_t* d_cell_start, const int32_t* d_cell_idx, const uint8_t* d_desc,
+                                               const uint8_t* d_taken, float min_x, float min_y, float inv_w, float inv_h,
+                                               const orbx_guided_query* d_queries, int q_cap, const int32_t* d_nq, int level_up,
+                                               int max_dist, int check_orientation, int32_t* d_match, int32_t* d_query_match,
+                                               int32_t* d_nmatches, int sync) {
+    static_assert(sizeof(orbx_guided_query) == sizeof(LocalQuery), "query layout");
+    if (!c || !d_kps_un || !d_cell_start || !d_cell_idx || !d_desc || !d_queries || !d_nq || !d_match || !d_query_match ||
+        !d_nmatches || n < 1 || kp_cap < 1 || q_cap < 1 || level_up < 0 || level_up > 1 || max_dist < 0 || max_dist > 256)
+        return ORBX_E_INVALID;
+    if (q_cap >= (1 << 30) || kp_cap >= (1 << 20)) return ORBX_E_CAPACITY;
+    HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    { int rc_ = ensure(c, &c->d_proj_minq, (size_t)n * kp_cap * 4); if (rc_) return rc_; }
+    { int rc_ = ensure(c, &c->d_proj_state, (size_t)n * kp_cap * 4); if (rc_) return rc_; }
+    { int rc_ = ensure(c, &c->d_proj_list, (size_t)n * q_cap * 8); if (rc_) return rc_; }
+    { int rc_ = ensure(c, &c->d_local_pick, (size_t)n * q_cap * 8); if (rc_) return rc_; }
+    { int rc_ = join(c); if (rc_) return rc_; }
+    LocalDev D;
+    D.W = {d_kps_un, d_cell_start, d_cell_idx, d_desc, nullptr, nullptr, min_x, min_y, inv_w, inv_h, kp_cap, q_cap};
+    for (int i = 0; i < ORBX_MAX_LEVELS; ++i) D.scale[i] = c->tab.scale[std::min(i, c->prm.nlevels - 1)];
+    D.th = 1.0f;
+    D.nn_ratio = 1.0f;
+    D.queries = reinterpret_cast<const LocalQuery*>(d_queries);
+    D.n_q = d_nq;
+    D.taken0 = d_taken;
+    D.match = d_match;
+    D.query_match = d_query_match;
+    D.n_matches = d_nmatches;
+    D.minq = (int32_t*)c->d_proj_minq.p;
+    D.held = (int32_t*)c->d_proj_state.p;
+    D.list = (int32_t*)c->d_proj_list.p;
+    D.pick = (int2*)c->d_local_pick.p;
+    D.max_dist = max_dist;
+    D.level_up = level_up;
+    D.check_orientation = check_orientation ? 1 : 0;
+    const size_t lds = ((size_t)2 * kp_cap + (size_t)2 * q_cap) * 4;
+    D.use_lds = lds <= 64 * 1024 ? 1 : 0;
+    hipLaunchKernelGGL(k_search_local<true>, dim3(n), dim3(kProjThreads), D.use_lds ? lds : 0, c->stream, D);
     HIP_TRY(c, hipGetLastError());
     if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     return ORBX_OK;

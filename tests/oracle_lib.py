@@ -393,6 +393,37 @@ def search_local_map(xy, octave, desc, u_right, taken0, cell_start, cell_idx, sc
     return n, match[:n_kp], qmatch[:len(q)]
 
 
+GUIDED_QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("angle", "<f4"), ("level", "<i4"), ("radius", "<f4"), ("flags", "<i4"),
+                               ("desc", "u1", (32,))])
+assert GUIDED_QUERY_DTYPE.itemsize == 56
+
+
+def search_guided(xy, octave, angle, desc, taken0, cell_start, cell_idx, min_x, min_y, inv_w, inv_h, queries, level_up, max_dist,
+                  check_orientation):
+    """The matching loops of SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (level_up 1) and
+    SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (level_up 0) on projected map points (GUIDED_QUERY_DTYPE), one
+    after the other; returns (nmatches, map point per feature, feature per query)."""
+    L = lib()
+    vp = C.c_void_p
+    L.orc_search_guided.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, vp, vp]
+    xy = np.ascontiguousarray(xy, np.float32)
+    octave = np.ascontiguousarray(octave, np.int32)
+    angle = np.ascontiguousarray(angle, np.float32)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    cell_start = np.ascontiguousarray(cell_start, np.int32)
+    cell_idx = np.ascontiguousarray(cell_idx, np.int32)
+    q = np.ascontiguousarray(queries, GUIDED_QUERY_DTYPE)
+    tk_a = None if taken0 is None else np.ascontiguousarray(taken0, np.uint8)
+    n_kp = len(octave)
+    match = np.full(max(n_kp, 1), -1, np.int32)
+    qmatch = np.full(max(len(q), 1), -1, np.int32)
+    n = L.orc_search_guided(_ptr(xy), _ptr(octave), _ptr(angle), _ptr(desc), n_kp, None if tk_a is None else _ptr(tk_a),
+                            _ptr(cell_start), _ptr(cell_idx), min_x, min_y, inv_w, inv_h, _ptr(q), len(q), int(level_up),
+                            int(max_dist), int(check_orientation), _ptr(match), _ptr(qmatch))
+    return n, match[:n_kp], qmatch[:len(q)]
+
+
 def stereo_from_rgbd(depth, factor, kps_xy, un_x, mbf):
     """Frame::ComputeStereoFromRGBD on a 2-D depth map (uint16 or float32) that GrabImageRGBD would scale by `factor`;
     returns (mvuRight, mvDepth)."""
