@@ -259,6 +259,18 @@ int orbx_search_window_batch_device(orbx_ctx* ctx, int n, const orbx_kp* d_kps_u
                                     const int32_t* d_nq, int32_t* d_best_idx, int32_t* d_best_dist, int sync);
 
 
+/* Replaces ORBVocabulary::score(v1, v2) for ORB-SLAM2's vocabulary (L1 norm: DBoW2 L1Scoring::score, reference
+ * Thirdparty/DBoW2/DBoW2/ScoringObject.cpp:23-68; called once per candidate keyframe from
+ * KeyFrameDatabase::DetectLoopCandidates, src/KeyFrameDatabase.cc:133, DetectRelocalizationCandidates, :249, and
+ * LoopClosing::DetectLoop, src/LoopClosing.cc:137) for a batch of pairs of BowVectors as
+ * orbx_bow_transform_batch_device leaves them (ascending word ids with their values): pair p scores vector
+ * d_pairs[2p] of the first set (d_bow_*_1, rows of cap_1 entries) against vector d_pairs[2p + 1] of the second set
+ * (which may be the same arrays).  d_score[p] is the reference's double, bit for bit (its callers narrow it to
+ * float). */
+int orbx_bow_score_l1_batch_device(orbx_ctx* ctx, int n_pairs, const uint32_t* d_bow_id_1, const double* d_bow_val_1,
+                                   const int32_t* d_bow_n_1, int cap_1, const uint32_t* d_bow_id_2, const double* d_bow_val_2,
+                                   const int32_t* d_bow_n_2, int cap_2, const int32_t* d_pairs, double* d_score, int sync);
+
 /* Replaces the search inside ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, th) (reference
  * src/ORBmatcher.cc:929-986; KeyFrame::GetFeaturesInArea, src/KeyFrame.cc:575-614; called from
  * LocalMapping::SearchInNeighbors, src/LocalMapping.cc:573 and :601) for a batch of keyframes: query i of keyframe f

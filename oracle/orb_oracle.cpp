@@ -1995,3 +1995,26 @@ extern "C" int orc_search_guided(const float* kps_xy, const int32_t* octave, con
     }
     return nmatches;
 }
+
+// DBoW2 L1Scoring::score (reference Thirdparty/DBoW2/DBoW2/ScoringObject.cpp:23-68), what ORBVocabulary::score computes
+// for ORB-SLAM2's vocabulary (L1_NORM; called from KeyFrameDatabase::DetectLoopCandidates, src/KeyFrameDatabase.cc:133,
+// DetectRelocalizationCandidates, :249, and LoopClosing::DetectLoop, src/LoopClosing.cc:137): both BowVectors as
+// ascending (word id, value) arrays.
+extern "C" double orc_bow_score_l1(const uint32_t* id1, const double* v1, int n1, const uint32_t* id2, const double* v2, int n2) {
+    int a = 0, b = 0;
+    double score = 0;
+    while (a < n1 && b < n2) {
+        const double vi = v1[a], wi = v2[b];
+        if (id1[a] == id2[b]) {
+            score += std::fabs(vi - wi) - std::fabs(vi) - std::fabs(wi);  // :41
+            ++a;
+            ++b;
+        } else if (id1[a] < id2[b]) {
+            while (a < n1 && id1[a] < id2[b]) ++a;  // lower_bound (:50)
+        } else {
+            while (b < n2 && id2[b] < id1[a]) ++b;  // :56
+        }
+    }
+    score = -score / 2.0;  // :65
+    return score;
+}

@@ -314,6 +314,9 @@ int orc_search_guided(const float* kps_xy, const int32_t* octave, const float* a
                       float inv_w, float inv_h, const orc_local_query* q, int n_q, int level_up, int max_dist,
                       int check_orientation, int32_t* match, int32_t* query_match);
 
+/* DBoW2 L1Scoring::score (reference Thirdparty/DBoW2/DBoW2/ScoringObject.cpp:23-68). */
+double orc_bow_score_l1(const uint32_t* id1, const double* v1, int n1, const uint32_t* id2, const double* v2, int n2);
+
 #ifdef __cplusplus
 }
 #endif

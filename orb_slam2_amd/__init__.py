@@ -57,7 +57,7 @@ EXPORTS = [
     "orbx_stereo_match_batch_device_noalloc", "orbx_search_local_map_batch_device", "orbx_search_by_bow_batch_device",
     "orbx_search_by_bow_keyframes_batch_device", "orbx_rgbd_depth_batch_device",
     "orbx_search_for_initialization_batch_device", "orbx_search_for_triangulation_batch_device",
-    "orbx_fuse_search_batch_device", "orbx_search_guided_batch_device",
+    "orbx_fuse_search_batch_device", "orbx_search_guided_batch_device", "orbx_bow_score_l1_batch_device",
 ]
 
 _lib = None
@@ -111,6 +111,7 @@ def load_library():
     L.orbx_fuse_search_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, f32, f32, f32, f32, vp, i32, vp, vp, vp, i32]
     L.orbx_search_guided_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, f32, f32, f32, f32, vp, i32, vp, i32, i32, i32,
                                                   vp, vp, vp, i32]
+    L.orbx_bow_score_l1_batch_device.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32]
     L.orbx_gray_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, i32, i32, vp, i32, C.c_size_t, i32]
     L.orbx_remap_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, vp, vp, i32, vp, i32, i32, i32,
                                           C.c_size_t, i32]
@@ -349,6 +350,15 @@ class ORBextractor:
             self._ctx, voc._v, n, C.c_void_p(d_desc), kp_cap, C.c_void_p(d_n), levelsup, C.c_void_p(d_word),
             C.c_void_p(d_node), C.c_void_p(d_weight), C.c_void_p(d_bow_id), C.c_void_p(d_bow_val), C.c_void_p(d_bow_n),
             C.c_void_p(d_fv_node), C.c_void_p(d_fv_idx), C.c_void_p(d_fv_n), int(sync)), self._ctx)
+
+    def bow_score_l1_batch_device(self, n_pairs, d_bow_id_1, d_bow_val_1, d_bow_n_1, cap_1, d_bow_id_2, d_bow_val_2, d_bow_n_2,
+                                  cap_2, d_pairs, d_score, sync=True):
+        """ORBVocabulary::score (L1 norm, DBoW2 ScoringObject.cpp:23-68) for a batch of pairs of BowVectors; see
+        orbx_bow_score_l1_batch_device."""
+        _check(self._L.orbx_bow_score_l1_batch_device(
+            self._ctx, n_pairs, C.c_void_p(d_bow_id_1), C.c_void_p(d_bow_val_1), C.c_void_p(d_bow_n_1), cap_1,
+            C.c_void_p(d_bow_id_2), C.c_void_p(d_bow_val_2), C.c_void_p(d_bow_n_2), cap_2, C.c_void_p(d_pairs),
+            C.c_void_p(d_score), int(sync)), self._ctx)
 
     def search_window_batch_device(self, n, d_kps_un, kp_cap, d_cell_start, d_cell_idx, d_desc, d_u_right, d_taken, min_x,
                                    min_y, inv_w, inv_h, d_queries, q_cap, d_nq, d_best_idx, d_best_dist, sync=True):

@@ -381,6 +381,60 @@ __global__ __launch_bounds__(256) void k_search_window(WindowDev W, const Window
     }
 }
 
+// ---- ORBVocabulary::score for the L1 norm ----------------------------------------------------
+// DBoW2 L1Scoring::score (reference Thirdparty/DBoW2/DBoW2/ScoringObject.cpp:23-68; called per candidate keyframe
+// from KeyFrameDatabase::DetectLoopCandidates, src/KeyFrameDatabase.cc:133, DetectRelocalizationCandidates, :249,
+// and LoopClosing::DetectLoop, src/LoopClosing.cc:137): the sum of |vi - wi| - |vi| - |wi| over the words both
+// BowVectors hold, accumulated in ascending word order, then -sum / 2.  One wave per pair: the lanes look their
+// 64 entries of the first vector up in the second (binary search), and the terms of the words found are added
+// one after the other in lane order, which is the reference's order.
+struct BowScoreDev {
+    const uint32_t *id_1, *id_2;   // [m_k][cap_k] ascending word ids (what the bag-of-words transform leaves)
+    const double *val_1, *val_2;   // [m_k][cap_k]
+    const int32_t *n_1, *n_2;      // [m_k]
+    int32_t cap_1, cap_2, n_pairs;
+    const int32_t* pairs;          // [n_pairs][2]: vector of the first set, vector of the second set
+    double* score;                 // [n_pairs]
+};
+
+// grid = ceil(n_pairs / 4), block = 256 (a wave per pair).
+__global__ __launch_bounds__(256) void k_bow_score_l1(BowScoreDev D) {
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= D.n_pairs) return;  // whole waves leave together
+    const int i = D.pairs[2 * p], j = D.pairs[2 * p + 1];
+    const int n1 = max(0, min(D.n_1[i], D.cap_1)), n2 = max(0, min(D.n_2[j], D.cap_2));
+    const uint32_t* id1 = D.id_1 + (size_t)i * D.cap_1;
+    const uint32_t* id2 = D.id_2 + (size_t)j * D.cap_2;
+    const double* v1 = D.val_1 + (size_t)i * D.cap_1;
+    const double* v2 = D.val_2 + (size_t)j * D.cap_2;
+    double score = 0.0;
+    for (int c = 0; c < n1; c += 64) {
+        const int e = c + lane;
+        double term = 0.0;
+        bool common = false;
+        if (e < n1) {
+            const uint32_t w = id1[e];
+            int lo = 0, hi = n2;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (id2[mid] < w) lo = mid + 1; else hi = mid;
+            }
+            if (lo < n2 && id2[lo] == w) {
+                const double vi = v1[e], wi = v2[lo];
+                term = __dsub_rn(__dsub_rn(fabs(__dsub_rn(vi, wi)), fabs(vi)), fabs(wi));  // :41
+                common = true;
+            }
+        }
+        unsigned long long m = __ballot(common);
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            score = __dadd_rn(score, __shfl(term, b, 64));
+        }
+    }
+    if (lane == 0) D.score[p] = __ddiv_rn(-score, 2.0);  // :65
+}
+
 // ---- the search of ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) --------------------
 // (reference src/ORBmatcher.cc:929-986 with KeyFrame::GetFeaturesInArea, src/KeyFrame.cc:575-614): a projected map
 // point looks for the most similar keypoint of the keyframe in its window, on the predicted level or the one

@@ -1548,6 +1548,22 @@ extern "C" int orbx_search_window_batch_device(orbx_ctx* c, int n, const orbx_kp
     return ORBX_OK;
 }
 
+extern "C" int orbx_bow_score_l1_batch_device(orbx_ctx* c, int n_pairs, const uint32_t* d_bow_id_1, const double* d_bow_val_1,
+                                              const int32_t* d_bow_n_1, int cap_1, const uint32_t* d_bow_id_2,
+                                              const double* d_bow_val_2, const int32_t* d_bow_n_2, int cap_2,
+                                              const int32_t* d_pairs, double* d_score, int sync) {
+    if (!c || !d_bow_id_1 || !d_bow_val_1 || !d_bow_n_1 || !d_bow_id_2 || !d_bow_val_2 || !d_bow_n_2 || !d_pairs || !d_score ||
+        n_pairs < 1 || cap_1 < 1 || cap_2 < 1)
+        return ORBX_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    { int rc_ = join(c); if (rc_) return rc_; }
+    BowScoreDev D = {d_bow_id_1, d_bow_id_2, d_bow_val_1, d_bow_val_2, d_bow_n_1, d_bow_n_2, cap_1, cap_2, n_pairs, d_pairs, d_score};
+    hipLaunchKernelGGL(k_bow_score_l1, dim3((n_pairs + 3) / 4), dim3(256), 0, c->stream, D);
+    HIP_TRY(c, hipGetLastError());
+    if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
+    return ORBX_OK;
+}
+
 extern "C" int orbx_fuse_search_batch_device(orbx_ctx* c, int n, const orbx_kp* d_kps_un, int kp_cap,
                                              const int32_t* d_cell_start, const int32_t* d_cell_idx, const uint8_t* d_desc,
                                              const float* d_u_right, float min_x, float min_y, float inv_w, float inv_h,

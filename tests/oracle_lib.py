@@ -479,6 +479,18 @@ def search_by_bow_keyframes(fv_node_1, fv_idx_1, desc_1, angle_1, valid_1, fv_no
     return n, match[:n_1]
 
 
+def bow_score_l1(id1, v1, id2, v2):
+    """DBoW2 L1Scoring::score (reference Thirdparty/DBoW2/DBoW2/ScoringObject.cpp:23-68) of two BowVectors given as ascending
+    word ids with their values."""
+    L = lib()
+    L.orc_bow_score_l1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_bow_score_l1.restype = C.c_double
+    a, b = np.ascontiguousarray(id1, np.uint32), np.ascontiguousarray(id2, np.uint32)
+    x, y = np.ascontiguousarray(v1, np.float64), np.ascontiguousarray(v2, np.float64)
+    assert len(a) == len(x) and len(b) == len(y)
+    return L.orc_bow_score_l1(_ptr(a), _ptr(x), len(a), _ptr(b), _ptr(y), len(b))
+
+
 def fuse_search(xy, octave, desc, u_right, cell_start, cell_idx, min_x, min_y, inv_w, inv_h, u, v, ur, radius, level,
                 inv_level_sigma2, q_desc):
     """The search of ORBmatcher::Fuse(pKF, vpMapPoints, th) for one projected map point (reference src/ORBmatcher.cc:929-986);
