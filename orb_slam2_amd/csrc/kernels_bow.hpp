@@ -531,7 +531,7 @@ struct ProjDev {
 
 constexpr int kProjThreads = 1024;
 constexpr int kProjCache = 8;
-constexpr int kProjLocal = 4;  // list entries per thread whose choice stays in a register between the phases of a round
+constexpr int kProjLocal = 2;  // list entries per thread whose choice stays in a register between the phases of a round
 constexpr int kHistoLength = 30, kThHigh = 100;  // ORBmatcher.cc:37-39
 
 __device__ __forceinline__ int proj_rot_bin(float last_angle, float cur_angle) {
@@ -596,7 +596,7 @@ __device__ __forceinline__ int proj_cached_choice(uint32_t ent, const uint2* cac
 }
 
 // grid = frames, block = 1024 (64 groups of sixteen lanes).
-__global__ __launch_bounds__(kProjThreads) void k_search_projection(ProjDev D) {
+__global__ __launch_bounds__(kProjThreads, 8) void k_search_projection(ProjDev D) {
     __shared__ float s_T[12];
     __shared__ int s_dir, s_left, s_nm, s_hist[kHistoLength], s_keep[3], s_cnt[kProjThreads / 16];
     const int f = blockIdx.x, tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
@@ -726,7 +726,9 @@ __global__ __launch_bounds__(kProjThreads) void k_search_projection(ProjDev D) {
             const int q = (int)(ent & 0x3FFFFFFFu);
             int win;
             if (round > 0 && !(ent >> 31) && i < kProjLocal) {
-                win = i == 0 ? ch[0] : i == 1 ? ch[1] : i == 2 ? ch[2] : ch[3];
+                win = ch[0];
+#pragma unroll
+                for (int k = 1; k < kProjLocal; ++k) win = i == k ? ch[k] : win;
                 if (win < 0) {
                     qm[q] = -1;
                     continue;
@@ -863,7 +865,7 @@ __device__ __forceinline__ void top2_row_merge(uint32_t& k1, uint32_t& k2, int& 
 // (u, v, angle of the map point's keypoint, predicted level, radius, flags, descriptor).
 // grid = frames, block = 1024 (64 groups of sixteen lanes).
 template <bool GUIDED>
-__global__ __launch_bounds__(kProjThreads) void k_search_local(LocalDev D) {
+__global__ __launch_bounds__(kProjThreads, 8) void k_search_local(LocalDev D) {
     __shared__ int s_left, s_nm, s_hist[kHistoLength], s_keep[3];
     const int f = blockIdx.x, tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
     const int kp_cap = D.W.kp_cap, q_cap = D.W.q_cap;

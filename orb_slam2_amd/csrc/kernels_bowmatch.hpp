@@ -70,7 +70,7 @@ __device__ __forceinline__ int bow_run_end(const uint32_t* nodes, int from, int 
 // feature | rotation bin << 24; after all runs the 30-bin histogram decides which bins stay (:267-288,
 // ComputeThreeMaxima :1638-1679) and a last pass over the frame's features strips or clears the entries.
 // grid = pairs, block = 1024, dynamic LDS = 16 waves * taken_words * 64 * 4 bytes.
-__global__ __launch_bounds__(kBowMatchThreads) void k_search_bow(BowMatchDev D) {
+__global__ __launch_bounds__(kBowMatchThreads, 8) void k_search_bow(BowMatchDev D) {
     extern __shared__ uint32_t s_taken[];
     __shared__ int s_nm, s_hist[kHistoLength], s_keep[3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, f = blockIdx.x;
@@ -234,7 +234,7 @@ struct TriDev {
 };
 
 // grid = pairs, block = 1024: 64 groups of sixteen lanes, a group per feature of the first keyframe's FeatureVector.
-__global__ __launch_bounds__(kBowMatchThreads) void k_search_triangulation(TriDev D) {
+__global__ __launch_bounds__(kBowMatchThreads, 8) void k_search_triangulation(TriDev D) {
     __shared__ int s_hist[kHistoLength], s_keep[3], s_nm;
     const int f = blockIdx.x, tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
     const int cap_1 = D.cap_1, cap_2 = D.cap_2;
