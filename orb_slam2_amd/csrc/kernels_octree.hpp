@@ -25,6 +25,7 @@ namespace orbx {
 constexpr uint32_t kNoSplit = 0xFFFFFFFFu;
 constexpr int kPtBatch = 8;  // global loads in flight per thread in the loops over the points
 constexpr int kOctWideFrom = 1000;  // levels that keep more features than this get 1024 threads
+constexpr int kOctWideBelowBlocks = 64;  // (frame, level) pairs of a launch up to which the wide workgroup is used whatever the level size
 
 // Block-wide exclusive scan of one int per thread (NT threads = NT / 64 waves).
 // Returns the exclusive prefix; *total receives the block sum.  Contains two barriers.

@@ -622,8 +622,9 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     }
     if ((rc = mark(kEvOct0, so))) return rc;
     // 1024 threads per (frame, level) when a level keeps more than a thousand features (the loops over the
-    // points and the rank-by-counting of the nodes are then long), else 256
-    if (c->max_kp_level > kOctWideFrom)
+    // points and the rank-by-counting of the nodes are then long) or when the batch is so small that the launch
+    // leaves most of the GPU idle anyway (a single frame: the level's sweeps are the critical path), else 256
+    if (c->max_kp_level > kOctWideFrom || n * L <= kOctWideBelowBlocks)
         hipLaunchKernelGGL(k_octree<1024>, dim3(n, L), dim3(1024), c->oct_lds, so, B, (const uint32_t*)c->d_cand[kp_set].p,
                            (const uint32_t*)c->d_ccount[kp_set].p, (uint32_t*)c->d_dense_pts.p, (uint16_t*)c->d_dense_node.p,
                            (uint32_t*)c->d_lvl_kps[kp_set].p, (int32_t*)c->d_lvl_count[kp_set].p);
