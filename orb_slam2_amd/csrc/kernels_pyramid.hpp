@@ -244,6 +244,49 @@ __global__ __launch_bounds__(256) void k_resize_rows(const uint8_t* __restrict__
     }
 }
 
+// Up to three pyramid levels in ONE launch, for a launch of a few frames, where the pyramid is seven kernels that
+// wait for one another and do microseconds of work each.  A level's pixel is a function of four pixels of the level
+// below, so level l+2 (and l+3) can be evaluated from level l directly by evaluating the pixels in between on the
+// way -- the same arithmetic in the same order, hence the same bytes -- at 4x (16x) the loads, which a launch of one
+// frame does not notice.  Thread = one destination pixel of one of the chain's levels.
+struct ResizeChain {
+    const uint8_t* src;           // level l, frames splane apart
+    int spitch;
+    uint64_t splane;
+    int nlev;                     // levels produced: l+1 .. l+nlev (1..3)
+    uint8_t* dst[3];
+    int dpitch[3];
+    uint64_t dplane[3];
+    int dw[3], dh[3];
+    const ResizeTap* xt[3];       // taps of level l+1+k into level l+k
+    const ResizeTap* yt[3];
+};
+
+template <int K>
+__device__ __forceinline__ int resize_chain_px(const ResizeChain& C, const uint8_t* S, int x, int y) {
+    if constexpr (K < 0) {
+        return S[(uint64_t)y * C.spitch + x];
+    } else {
+        const ResizeTap tx = C.xt[K][x], ty = C.yt[K][y];
+        const int a = resize_chain_px<K - 1>(C, S, tx.ofs, ty.ofs), b = resize_chain_px<K - 1>(C, S, tx.ofs1, ty.ofs);
+        const int c = resize_chain_px<K - 1>(C, S, tx.ofs, ty.ofs1), d = resize_chain_px<K - 1>(C, S, tx.ofs1, ty.ofs1);
+        const int t0 = a * tx.c0 + b * tx.c1, t1 = c * tx.c0 + d * tx.c1;
+        const int v = (((ty.c0 * (t0 >> 4)) >> 16) + ((ty.c1 * (t1 >> 4)) >> 16) + 2) >> 2;
+        return min(max(v, 0), 255);
+    }
+}
+
+// grid = (ceil(max pixels of a level / 256), nlev, frames), block = 256.
+__global__ __launch_bounds__(256) void k_resize_chain(ResizeChain C) {
+    const int k = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int w = C.dw[k];
+    if (i >= w * C.dh[k]) return;
+    const int y = i / w, x = i - y * w;
+    const uint8_t* S = C.src + (uint64_t)blockIdx.z * C.splane;
+    const int v = k == 0 ? resize_chain_px<0>(C, S, x, y) : k == 1 ? resize_chain_px<1>(C, S, x, y) : resize_chain_px<2>(C, S, x, y);
+    C.dst[k][(uint64_t)blockIdx.z * C.dplane[k] + (uint64_t)y * C.dpitch[k] + x] = (uint8_t)v;
+}
+
 __device__ __forceinline__ int reflect101(int p, int len) {
     p = p < 0 ? -p : p;
     return p >= len ? 2 * len - 2 - p : p;

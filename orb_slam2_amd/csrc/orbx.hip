@@ -41,6 +41,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // small static arrays.  The limit is a property of the kernel on a device, shared by every context,
 // so it is set to this one value and never to a context's own need.
 constexpr int kMaxDynamicLds = 160 * 1024 - 256;
+constexpr uint64_t kResizeChainMaxPixels = 1u << 19;  // launches of up to this many level-0 pixels build the pyramid three levels per launch
 constexpr int kPipeSlots = 3;  // pinned upload slots and pinned result slots of the pipelined host batch path
 
 // Scratch of the entry point that allocates nothing (orbx_stereo_match_batch_device_noalloc): a
@@ -562,7 +563,30 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     }
     // stage 0 (aux): pyramid
     if ((rc = mark(kEvPyr0, aux))) return rc;
-    for (int l = 1; l < L; ++l) {
+    // a launch of a few frames: three levels per launch (k_resize_chain) instead of one
+    const bool chain = !c->dbg_resize_tiles && (uint64_t)n * B.lv[0].w * B.lv[0].h <= kResizeChainMaxPixels;
+    for (int l = 1; chain && l < L; l += 3) {
+        const LevelDev& S = B.lv[l - 1];
+        ResizeChain C;
+        C.src = S.img;
+        C.spitch = S.pitch;
+        C.splane = S.plane;
+        C.nlev = std::min(3, L - l);
+        int px = 0;
+        for (int k = 0; k < 3; ++k) {
+            const LevelDev& D = B.lv[std::min(l + k, L - 1)];
+            C.dst[k] = const_cast<uint8_t*>(D.img);
+            C.dpitch[k] = D.pitch;
+            C.dplane[k] = D.plane;
+            C.dw[k] = D.w;
+            C.dh[k] = D.h;
+            C.xt[k] = (const ResizeTap*)c->d_xt[std::min(l + k, L - 1)].p;
+            C.yt[k] = (const ResizeTap*)c->d_yt[std::min(l + k, L - 1)].p;
+            if (k < C.nlev) px = std::max(px, D.w * D.h);
+        }
+        hipLaunchKernelGGL(k_resize_chain, dim3((px + 255) / 256, C.nlev, n), dim3(256), 0, aux, C);
+    }
+    for (int l = 1; !chain && l < L; ++l) {
         const LevelDev& S = B.lv[l - 1];
         const LevelDev& D = B.lv[l];
         // the resize-tiles switch (diagnostic) keeps the LDS-tiled kernel for every level
