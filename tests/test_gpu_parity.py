@@ -295,8 +295,10 @@ def test_parameter_space(oracle, w, h, nf, scale, nl, ini, mn, cid):
 
 
 def test_resize_tiled_kernel(oracle, monkeypatch):
-    """The pyramid has two resize kernels: the streaming one (taps of four columns within eight source
-    bytes) and the LDS-tiled one for everything else.  The diagnostic switch forces the tiled one."""
+    """The pyramid has three resize kernels: the streaming one (taps of four columns within eight source
+    bytes), the LDS-tiled one for everything else, and for a launch of one small frame the one that produces
+    three levels per launch (the single-frame tests above run through it, the batch tests through the first
+    two).  The diagnostic switch forces the tiled one."""
     monkeypatch.setenv("ORBX_RESIZE_TILES", "1")
     w, h = 752, 480
     img = synth.make_frame(w, h, 4, 3)
