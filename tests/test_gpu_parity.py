@@ -111,6 +111,50 @@ def test_pipelined_host_batch(oracle, monkeypatch):
     ex.close()
 
 
+def test_pipelined_host_batch_two_threads_changing_sizes(oracle):
+    """The host batch path runs a staging and a delivery thread beside the caller: two contexts called from two threads
+    at the same time, with batch and chunk sizes that change from call to call, return for every frame what the
+    oracle returns for it."""
+    import ctypes as C
+    import threading
+    w, h, nf, nmax = 320, 240, 300, 40
+    base = synth.make_batch(6, w, h, 2, 123)
+    orc = oracle.Oracle(nf, 1.2, 6, 20, 7)
+    expect = [orc.extract(f) for f in base]
+    failures = []
+
+    def worker(tid):
+        rng = np.random.default_rng(tid)
+        ex = oa.ORBextractor(nf, 1.2, 6, 20, 7, max_width=w, max_height=h, max_batch=nmax, keep_pyramid=False)
+        cap = ex.max_keypoints(w, h)
+        for call in range(12):
+            n = int(rng.integers(16, nmax + 1))           # 16 frames and more take the pipelined path
+            ex.set_debug_flag(oa.FLAG_PIPE_CHUNK, int(rng.choice([0, 5, 16, 33])))
+            order = rng.integers(0, len(base), n)
+            frames = [np.ascontiguousarray(base[i]) for i in order]
+            kps, desc, cnt = np.zeros((n, cap), oa.KP_DTYPE), np.zeros((n, cap, 32), np.uint8), np.zeros(n, np.int32)
+            ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+            strides = (C.c_int * n)(*[f.strides[0] for f in frames])
+            rc = ex._L.orbx_extract_batch(ex._ctx, n, ptrs, w, h, strides, kps.ctypes.data_as(C.c_void_p), cap,
+                                          desc.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p))
+            if rc != 0:
+                failures.append("thread %d call %d: rc %d" % (tid, call, rc))
+                break
+            for j, i in enumerate(order):
+                okps, odesc = expect[int(i)]
+                k = int(cnt[j])
+                if k != len(okps) or kps[j, :k].tobytes() != okps.tobytes() or not (desc[j, :k] == odesc).all():
+                    failures.append("thread %d call %d frame %d" % (tid, call, j))
+        ex.close()
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not failures, failures[:5]
+
+
 def test_strided_input_and_reuse(oracle):
     w, h = 640, 480
     big = np.zeros((h, w + 37), np.uint8)
