@@ -597,7 +597,7 @@ __device__ __forceinline__ int proj_cached_choice(uint32_t ent, const uint2* cac
 
 // grid = frames, block = 1024 (64 groups of sixteen lanes).
 __global__ __launch_bounds__(kProjThreads, 8) void k_search_projection(ProjDev D) {
-    __shared__ float s_T[12];
+    __shared__ float s_T[12], s_scale[ORBX_MAX_LEVELS];  // the scale table goes through LDS: a per-lane index into a kernel argument would put it in scratch memory
     __shared__ int s_dir, s_left, s_nm, s_hist[kHistoLength], s_keep[3], s_cnt[kProjThreads / 16];
     const int f = blockIdx.x, tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
     const int kp_cap = D.W.kp_cap, q_cap = D.W.q_cap;
@@ -620,6 +620,10 @@ __global__ __launch_bounds__(kProjThreads, 8) void k_search_projection(ProjDev D
     }
     for (int q = tid; q < q_cap; q += kProjThreads) qm[q] = -1;
     if (tid < 12) s_T[tid] = D.poses[(size_t)f * 24 + tid];
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < ORBX_MAX_LEVELS; ++i) s_scale[i] = D.scale[i];
+    }
     if (tid < kHistoLength) s_hist[tid] = 0;
     if (tid < kProjThreads / 16) s_cnt[tid] = 0;
     if (tid == 0) {
@@ -669,7 +673,7 @@ __global__ __launch_bounds__(kProjThreads, 8) void k_search_projection(ProjDev D
                 const float v = __fadd_rn(__fmul_rn(__fmul_rn(P.fy, c3[1]), invzc), P.cy);
                 if (!(invzc < 0) && !(u < P.min_x || u > P.max_x) && !(v < P.min_y || v > P.max_y)) {
                     const int oct = min(max(m->octave, 0), ORBX_MAX_LEVELS - 1);
-                    const float radius = __fmul_rn(P.th, D.scale[oct]);  // :1418
+                    const float radius = __fmul_rn(P.th, s_scale[oct]);  // :1418
                     const int lo = dir == 1 ? m->octave : (dir == 2 ? 0 : m->octave - 1);
                     const int hi = dir == 1 ? -1 : (dir == 2 ? m->octave : m->octave + 1);
                     const float ur = __fsub_rn(u, __fmul_rn(P.mbf, invzc));  // :1446
@@ -867,6 +871,7 @@ __device__ __forceinline__ void top2_row_merge(uint32_t& k1, uint32_t& k2, int& 
 template <bool GUIDED>
 __global__ __launch_bounds__(kProjThreads, 8) void k_search_local(LocalDev D) {
     __shared__ int s_left, s_nm, s_hist[kHistoLength], s_keep[3];
+    __shared__ float s_scale[ORBX_MAX_LEVELS];  // through LDS: a per-lane index into a kernel argument would put the table in scratch memory
     const int f = blockIdx.x, tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
     const int kp_cap = D.W.kp_cap, q_cap = D.W.q_cap;
     const int nq = min(D.n_q[f], q_cap);
@@ -885,7 +890,11 @@ __global__ __launch_bounds__(kProjThreads, 8) void k_search_local(LocalDev D) {
         match[i] = -1;
     }
     for (int q = tid; q < q_cap; q += kProjThreads) qm[q] = -1;
-    if (tid == 0) s_nm = 0;
+    if (tid == 0) {
+        s_nm = 0;
+#pragma unroll
+        for (int i = 0; i < ORBX_MAX_LEVELS; ++i) s_scale[i] = D.scale[i];
+    }
     __syncthreads();
 
     int n_list = nq;
@@ -904,7 +913,7 @@ __global__ __launch_bounds__(kProjThreads, 8) void k_search_local(LocalDev D) {
                 const int level = min(max(m->level, 0), ORBX_MAX_LEVELS - 1);
                 float r = (double)m->view_cos > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos (:131-137)
                 if (factor) r = __fmul_rn(r, D.th);
-                const float radius = GUIDED ? m->view_cos : __fmul_rn(r, D.scale[level]);  // :69; guided: the caller's (:1563, :360)
+                const float radius = GUIDED ? m->view_cos : __fmul_rn(r, s_scale[level]);  // :69; guided: the caller's (:1563, :360)
                 const uint32_t may_take = GUIDED ? (uint32_t)D.max_dist : (uint32_t)kThHigh;
                 const uint4 d0 = *reinterpret_cast<const uint4_unaligned*>(m->desc);
                 const uint4 d1 = *reinterpret_cast<const uint4_unaligned*>(m->desc + 16);
