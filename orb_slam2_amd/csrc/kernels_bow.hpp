@@ -302,12 +302,12 @@ __device__ __forceinline__ void window_best(const WindowDev& W, int f, float x, 
                 a = cs[c0 + nMinCellY];
                 len = cs[c0 + nMaxCellY + 1] - a;
             }
-            int incl = len;  // inclusive prefix over the group's sixteen lanes
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) {
-                const int t = __shfl_up(incl, d, 16);
-                if (sub >= d) incl += t;
-            }
+            // inclusive prefix over the group's sixteen lanes (one DPP row: shifts by 1, 2, 4, 8, zeros shifted in)
+            int incl = len;
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);
             const int total = __shfl(incl, gbase + 15, 64);
             const int shift = a - (incl - len);  // entry e of this lane's column is cell_idx[e + shift]
             // the sixteen lanes stay together through this loop: the shuffles read lanes of the whole group
