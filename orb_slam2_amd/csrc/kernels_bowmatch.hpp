@@ -48,6 +48,13 @@ __device__ __forceinline__ void bow_top2_merge(uint32_t& k1, uint32_t& k2, uint3
     k1 = lo;
 }
 
+template <int CTRL>
+__device__ __forceinline__ void bow_top2_merge_dpp(uint32_t& k1, uint32_t& k2) {
+    const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k1, CTRL, 0xF, 0xF, false);
+    const uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k2, CTRL, 0xF, 0xF, false);
+    bow_top2_merge(k1, k2, o1, o2);
+}
+
 // First index in [from, n) whose node differs from `node` (n if none), found by the wave 64 entries at a time.
 __device__ __forceinline__ int bow_run_end(const uint32_t* nodes, int from, int n, uint32_t node) {
     const int lane = threadIdx.x & 63;
@@ -162,8 +169,13 @@ __global__ __launch_bounds__(kBowMatchThreads, 8) void k_search_bow(BowMatchDev 
                         }
                     }
                 }
+                // inside a row of sixteen lanes through DPP (pairs, quads, halves, the row), then across the four rows
+                bow_top2_merge_dpp<0xB1>(k1, k2);
+                bow_top2_merge_dpp<0x4E>(k1, k2);
+                bow_top2_merge_dpp<0x141>(k1, k2);
+                bow_top2_merge_dpp<0x140>(k1, k2);
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
+                for (int off = 16; off < 64; off <<= 1) {
                     const uint32_t o1 = (uint32_t)__shfl_xor((int)k1, off), o2 = (uint32_t)__shfl_xor((int)k2, off);
                     bow_top2_merge(k1, k2, o1, o2);
                 }

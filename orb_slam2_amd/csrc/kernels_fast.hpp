@@ -7,16 +7,23 @@
 
 namespace orbx {
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP adds (row shifts 1, 2, 4, 8 inside the rows of
+// 16 lanes, then the row broadcasts 15 and 31); lanes a shift does not reach add 0.
+__device__ __forceinline__ int wave_incl_scan(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+    return x;
+}
+
 // Block-wide exclusive scan of one int per thread (256 threads = 4 waves).
 // Returns the exclusive prefix; *total receives the block sum.  Contains two barriers.
 __device__ __forceinline__ int block_excl_scan_256(int v, int* s_wave4, int* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(incl, d);
-        if (lane >= d) incl += t;
-    }
+    const int incl = wave_incl_scan(v);
     __syncthreads();  // protects s_wave4 against a previous use
     if (lane == 63) s_wave4[wave] = incl;
     __syncthreads();
@@ -98,18 +105,6 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
     uint32_t r;
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(a), "v"(b));
     return r;
-}
-
-// Inclusive prefix sum over the 64 lanes of a wave with DPP adds (row shifts 1, 2, 4, 8 inside the rows of
-// 16 lanes, then the row broadcasts 15 and 31); lanes a shift does not reach add 0.
-__device__ __forceinline__ int wave_incl_scan(int x) {
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
-    return x;
 }
 
 // 1 / n for a small positive integer n as one v_rcp_f32 (1 ulp) instead of an IEEE division (11 instructions).

@@ -57,6 +57,15 @@ struct StereoDev {
 
 constexpr int kStereoKpPerBlock = 32;  // left keypoints per workgroup of k_stereo_search (8 per wave)
 
+// Minimum over an aligned group of eight lanes, left in all of them, through DPP (lane pairs, quads, the two quads
+// of a half row): no LDS round trip.  The eight lanes of a group are active together.
+__device__ __forceinline__ uint32_t min_over_8(uint32_t v) {
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false));  // row_half_mirror
+    return v;
+}
+
 // grid = pairs, block = 256, dynamic LDS = (rows + 1) * 4 bytes.
 __global__ __launch_bounds__(256) void k_stereo_rows(StereoDev S) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];  // rows + 1
@@ -193,8 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             m = mn;
             k = kn;
         }
-#pragma unroll
-        for (int d = 4; d >= 1; d >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, d, 64));
+        key = min_over_8(key);
     }
 
     // ---- the group stages its two windows in LDS (:570-600)
@@ -305,8 +313,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         __builtin_amdgcn_wave_barrier();  // every partial sum was read
         qa[j] = (uint16_t)t0;
         if (j < 3) qa[8 + j] = (uint16_t)t1;
-#pragma unroll
-        for (int d = 4; d >= 1; d >>= 1) k2 = min(k2, (uint32_t)__shfl_xor((int)k2, d, 64));
+        k2 = min_over_8(k2);
         __builtin_amdgcn_wave_barrier();
         const int sb = (int)(k2 & 0xFFu);
         const int best_w = (int)(k2 >> 8);
