@@ -352,6 +352,48 @@ int orbx_search_local_map_batch_device(orbx_ctx* ctx, int n, const orbx_kp* d_kp
                                        const orbx_local_query* d_queries, int q_cap, const int32_t* d_nq,
                                        int32_t* d_match, int32_t* d_query_match, int32_t* d_nmatches, int sync);
 
+/* ---- in front of the searches: projecting map points ------------------------------------------
+ * orbx_is_in_frustum_batch_device replaces Frame::isInFrustum (reference src/Frame.cc:271-327) with
+ * MapPoint::PredictScale (src/MapPoint.cc:402-417) as Tracking::SearchLocalPoints calls it for every local map point
+ * (src/Tracking.cc:1340-1353), for a batch of frames: point i of frame f is moved into the camera frame of
+ * d_poses[f*12 ..] (rows of [Rcw | tcw]), must have a depth that is not negative, project inside
+ * [min_x, max_x] x [min_y, max_y], lie between 0.8 * min_dist and 1.2 * max_dist from the camera centre
+ * d_centres[f*3 ..] (Frame::mOw) and be seen at a cosine of at least view_cos_limit against its normal.  The record
+ * written for it is what orbx_search_local_map_batch_device reads: mTrackProjX / Y / XR, mnTrackScaleLevel,
+ * mTrackViewCos, the descriptor, flags bit 0 copied and bit 1 set when the point is skipped on input or not in
+ * view (mbTrackInView false).  d_n_in_view[f] = the points in view (nToMatch of src/Tracking.cc:1351).
+ *
+ * orbx_fuse_project_batch_device replaces the tests in front of the search of ORBmatcher::Fuse(pKF, vpMapPoints, th)
+ * (src/ORBmatcher.cc:881-927; KeyFrame::IsInImage, src/KeyFrame.cc:616-619): the same steps with that function's
+ * arithmetic (x / z first, half-open image bounds, PO . Pn >= 0.5 * dist in double), d_centres = pKF->GetCameraCenter().
+ * The records are the queries of orbx_fuse_search_batch_device: u, v, ur, radius = th * mvScaleFactors[level],
+ * levels level - 1 .. level; a point that is skipped on input (flags bit 1: NULL, isBad() or IsInKeyFrame(pKF)) or
+ * fails a test gets radius -1, an empty window, so its result is "no match".  d_n_projected[f] counts the others.
+ *
+ * The logarithm of PredictScale is the float nearest to log(max_dist / dist), which a C library's logf returns
+ * except for arguments within a fraction of an ulp of a rounding boundary.  log_scale_factor is
+ * Frame::mfLogScaleFactor (src/Frame.cc:71); the scale factors and the number of levels are the context's. */
+typedef struct orbx_frustum_point {
+    float x, y, z;            /* MapPoint::GetWorldPos */
+    float nx, ny, nz;         /* MapPoint::GetNormal */
+    float min_dist, max_dist; /* MapPoint::mfMinDistance, mfMaxDistance */
+    int32_t flags;            /* bit 0: Observations() > 0 (copied to the output); bit 1: skip */
+    uint8_t desc[32];         /* MapPoint::GetDescriptor */
+} orbx_frustum_point; /* 68 bytes */
+typedef struct orbx_frustum_params {
+    float fx, fy, cx, cy, mbf;           /* Frame::fx .. mbf */
+    float min_x, max_x, min_y, max_y;    /* mnMinX, mnMaxX, mnMinY, mnMaxY */
+    float view_cos_limit;                /* 0.5 in Tracking::SearchLocalPoints; not used by the Fuse variant */
+    float log_scale_factor;              /* mfLogScaleFactor */
+    float th;                            /* Fuse's th; not used by isInFrustum */
+} orbx_frustum_params;
+int orbx_is_in_frustum_batch_device(orbx_ctx* ctx, int n, const orbx_frustum_params* params, const float* d_poses,
+                                    const float* d_centres, const orbx_frustum_point* d_points, int q_cap,
+                                    const int32_t* d_nq, orbx_local_query* d_queries_out, int32_t* d_n_in_view, int sync);
+int orbx_fuse_project_batch_device(orbx_ctx* ctx, int n, const orbx_frustum_params* params, const float* d_poses,
+                                   const float* d_centres, const orbx_frustum_point* d_points, int q_cap,
+                                   const int32_t* d_nq, orbx_window_query* d_queries_out, int32_t* d_n_projected, int sync);
+
 /* Replaces the matching loops of ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th,
  * ORBdist) (reference src/ORBmatcher.cc:1509-1636; Tracking::Relocalization, src/Tracking.cc:1654 and :1670) and of
  * ORBmatcher::SearchByProjection(KeyFrame* pKF, Scw, vpPoints, vpMatched, th) (:290-403; LoopClosing::ComputeSim3,

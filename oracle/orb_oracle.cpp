@@ -2018,3 +2018,126 @@ extern "C" double orc_bow_score_l1(const uint32_t* id1, const double* v1, int n1
     score = -score / 2.0;  // :65
     return score;
 }
+
+// Natural logarithm of a positive finite float in double, from IEEE additions, multiplications and one division
+// (no libm call, so any IEEE machine computes the same bits): x = m * 2^e with m in (sqrt(1/2), sqrt(2)],
+// s = (m - 1) / (m + 1), log m = 2 s (1 + s^2/3 + ... + s^24/25).  Narrowed to float it is the correctly rounded
+// logf(x), which is what the reference's log(float) (src/MapPoint.cc:410) returns from a C library up to that
+// library's rounding of arguments that sit on a rounding boundary.
+extern "C" double orc_log_pinned(float x) {
+    int e = 0;
+    double m = 2.0 * std::frexp((double)x, &e);  // [1, 2), x = m * 2^(e - 1); both steps are exact
+    e -= 1;
+    if (m > 1.4142135623730951) {
+        m = m * 0.5;
+        e += 1;
+    }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double z = s * s;
+    double p = 1.0 / 25.0;
+    for (int k = 23; k >= 1; k -= 2) {
+        p = p * z;
+        p = p + 1.0 / (double)k;
+    }
+    const double hi = (double)e * 0.6931471805599453;
+    const double lo = (2.0 * s) * p;
+    return hi + lo;
+}
+
+// MapPoint::PredictScale (reference src/MapPoint.cc:402-417).  On x86-64 the conversion of a float that is not a
+// finite number of int range yields INT_MIN, which the clamp turns into level 0.
+static int predict_scale(float max_distance, float current_dist, float log_scale_factor, int n_levels) {
+    const float ratio = max_distance / current_dist;
+    if (!(ratio > 0.0f) || std::isinf(ratio)) return 0;  // logf: -inf, NaN or +inf
+    const float q = std::ceil((float)orc_log_pinned(ratio) / log_scale_factor);
+    int nScale;
+    if (!(q >= -2147483648.0f && q < 2147483648.0f)) nScale = INT32_MIN;
+    else nScale = (int)q;
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= n_levels) nScale = n_levels - 1;
+    return nScale;
+}
+
+// The steps Frame::isInFrustum (reference src/Frame.cc:271-327) and the first half of ORBmatcher::Fuse
+// (src/ORBmatcher.cc:881-927) share, with cv::Mat's arithmetic: gemm of a 3x3 by a 3x1 float matrix sums its
+// products left to right in float; cv::norm(NORM_L2) and cv::Mat::dot of three floats accumulate in double.
+struct Projected {
+    float pc[3], po[3], dist;
+    double dot;
+};
+static Projected project_point(const float T[12], const float Ow[3], const float P[3], const float Pn[3]) {
+    Projected r;
+    for (int k = 0; k < 3; k++) {
+        float acc = T[4 * k] * P[0];
+        acc = acc + T[4 * k + 1] * P[1];
+        acc = acc + T[4 * k + 2] * P[2];
+        r.pc[k] = acc + T[4 * k + 3];
+        r.po[k] = P[k] - Ow[k];
+    }
+    double n2 = 0.0, d = 0.0;
+    for (int k = 0; k < 3; k++) {
+        n2 += (double)r.po[k] * (double)r.po[k];
+        d += (double)r.po[k] * (double)Pn[k];
+    }
+    r.dist = (float)std::sqrt(n2);
+    r.dot = d;
+    return r;
+}
+
+// Frame::isInFrustum (reference src/Frame.cc:271-327) for one map point; cam = fx, fy, cx, cy, mbf; bounds = mnMinX,
+// mnMaxX, mnMinY, mnMaxY.  Returns mbTrackInView and fills mTrackProjX, mTrackProjY, mTrackProjXR,
+// mnTrackScaleLevel, mTrackViewCos.
+extern "C" int orc_is_in_frustum(const float Tcw[12], const float Ow[3], const float cam[5], const float bounds[4],
+                                 float viewing_cos_limit, float log_scale_factor, int n_levels, const float P[3],
+                                 const float Pn[3], float min_distance, float max_distance, float* proj_x, float* proj_y,
+                                 float* proj_xr, int* scale_level, float* view_cos) {
+    const Projected g = project_point(Tcw, Ow, P, Pn);
+    const float PcX = g.pc[0], PcY = g.pc[1], PcZ = g.pc[2];
+    if (PcZ < 0.0f) return 0;  // :285
+    const float invz = 1.0f / PcZ;
+    const float u = cam[0] * PcX * invz + cam[2];
+    const float v = cam[1] * PcY * invz + cam[3];
+    if (u < bounds[0] || u > bounds[1]) return 0;  // :293
+    if (v < bounds[2] || v > bounds[3]) return 0;
+    const float maxDistance = 1.2f * max_distance;  // MapPoint::GetMaxDistanceInvariance, src/MapPoint.cc:379-383
+    const float minDistance = 0.8f * min_distance;
+    const float dist = g.dist;
+    if (dist < minDistance || dist > maxDistance) return 0;  // :304
+    const float viewCos = (float)(g.dot / (double)dist);     // :310, double / float
+    if (viewCos < viewing_cos_limit) return 0;
+    *scale_level = predict_scale(max_distance, dist, log_scale_factor, n_levels);
+    *proj_x = u;
+    *proj_xr = u - cam[4] * invz;
+    *proj_y = v;
+    *view_cos = viewCos;
+    return 1;
+}
+
+// The tests ORBmatcher::Fuse(pKF, vpMapPoints, th) applies to a map point before it searches (reference
+// src/ORBmatcher.cc:881-927; KeyFrame::IsInImage, src/KeyFrame.cc:616-619).  Returns 0 when the point is dropped.
+extern "C" int orc_fuse_project(const float Tcw[12], const float Ow[3], const float cam[5], const float bounds[4],
+                                float log_scale_factor, int n_levels, const float* scale_factors, float th, const float P[3],
+                                const float Pn[3], float min_distance, float max_distance, float* u_out, float* v_out,
+                                float* ur_out, float* radius, int* predicted_level) {
+    const Projected g = project_point(Tcw, Ow, P, Pn);
+    if (g.pc[2] < 0.0f) return 0;  // :885
+    const float invz = 1 / g.pc[2];
+    const float x = g.pc[0] * invz;
+    const float y = g.pc[1] * invz;
+    const float u = cam[0] * x + cam[2];
+    const float v = cam[1] * y + cam[3];
+    if (!(u >= bounds[0] && u < bounds[1] && v >= bounds[2] && v < bounds[3])) return 0;  // IsInImage
+    const float ur = u - cam[4] * invz;
+    const float maxDistance = 1.2f * max_distance;
+    const float minDistance = 0.8f * min_distance;
+    const float dist3D = g.dist;
+    if (dist3D < minDistance || dist3D > maxDistance) return 0;  // :915
+    if (g.dot < 0.5 * dist3D) return 0;                           // :921
+    const int nPredictedLevel = predict_scale(max_distance, dist3D, log_scale_factor, n_levels);
+    *radius = th * scale_factors[nPredictedLevel];  // :927
+    *u_out = u;
+    *v_out = v;
+    *ur_out = ur;
+    *predicted_level = nPredictedLevel;
+    return 1;
+}

@@ -317,6 +317,21 @@ int orc_search_guided(const float* kps_xy, const int32_t* octave, const float* a
 /* DBoW2 L1Scoring::score (reference Thirdparty/DBoW2/DBoW2/ScoringObject.cpp:23-68). */
 double orc_bow_score_l1(const uint32_t* id1, const double* v1, int n1, const uint32_t* id2, const double* v2, int n2);
 
+/* log(x) of a positive finite float in double from IEEE operations only; (float) of it is the correctly rounded logf. */
+double orc_log_pinned(float x);
+
+/* Frame::isInFrustum (reference src/Frame.cc:271-327) with MapPoint::PredictScale (src/MapPoint.cc:402-417). */
+int orc_is_in_frustum(const float Tcw[12], const float Ow[3], const float cam[5], const float bounds[4],
+                      float viewing_cos_limit, float log_scale_factor, int n_levels, const float P[3], const float Pn[3],
+                      float min_distance, float max_distance, float* proj_x, float* proj_y, float* proj_xr, int* scale_level,
+                      float* view_cos);
+
+/* The tests in front of the search of ORBmatcher::Fuse(pKF, vpMapPoints, th) (reference src/ORBmatcher.cc:881-927). */
+int orc_fuse_project(const float Tcw[12], const float Ow[3], const float cam[5], const float bounds[4],
+                     float log_scale_factor, int n_levels, const float* scale_factors, float th, const float P[3],
+                     const float Pn[3], float min_distance, float max_distance, float* u_out, float* v_out, float* ur_out,
+                     float* radius, int* predicted_level);
+
 #ifdef __cplusplus
 }
 #endif

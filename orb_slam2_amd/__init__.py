@@ -58,6 +58,7 @@ EXPORTS = [
     "orbx_search_by_bow_keyframes_batch_device", "orbx_rgbd_depth_batch_device",
     "orbx_search_for_initialization_batch_device", "orbx_search_for_triangulation_batch_device",
     "orbx_fuse_search_batch_device", "orbx_search_guided_batch_device", "orbx_bow_score_l1_batch_device",
+    "orbx_is_in_frustum_batch_device", "orbx_fuse_project_batch_device",
 ]
 
 _lib = None
@@ -112,6 +113,8 @@ def load_library():
     L.orbx_search_guided_batch_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, f32, f32, f32, f32, vp, i32, vp, i32, i32, i32,
                                                   vp, vp, vp, i32]
     L.orbx_bow_score_l1_batch_device.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32]
+    L.orbx_is_in_frustum_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32]
+    L.orbx_fuse_project_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32]
     L.orbx_gray_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, i32, i32, vp, i32, C.c_size_t, i32]
     L.orbx_remap_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, vp, vp, i32, vp, i32, i32, i32,
                                           C.c_size_t, i32]
@@ -439,6 +442,24 @@ class ORBextractor:
             int(max_dist), int(check_orientation), C.c_void_p(d_match), C.c_void_p(d_query_match), C.c_void_p(d_nmatches),
             int(sync)), self._ctx)
 
+    def is_in_frustum_batch_device(self, n, params, d_poses, d_centres, d_points, q_cap, d_nq, d_queries_out, d_n_in_view,
+                                   sync=True):
+        """Frame::isInFrustum with MapPoint::PredictScale (src/Frame.cc:271-327, src/MapPoint.cc:402-417) for a batch of
+        frames and their local map points (FRUSTUM_POINT_DTYPE records in, LOCAL_QUERY_DTYPE records out); `params` is a
+        FrustumParams; see orbx_is_in_frustum_batch_device."""
+        _check(self._L.orbx_is_in_frustum_batch_device(
+            self._ctx, n, C.byref(params), C.c_void_p(d_poses), C.c_void_p(d_centres), C.c_void_p(d_points), q_cap,
+            C.c_void_p(d_nq), C.c_void_p(d_queries_out), C.c_void_p(d_n_in_view), int(sync)), self._ctx)
+
+    def fuse_project_batch_device(self, n, params, d_poses, d_centres, d_points, q_cap, d_nq, d_queries_out, d_n_projected,
+                                  sync=True):
+        """The tests in front of the search of ORBmatcher::Fuse(pKF, vpMapPoints, th) (src/ORBmatcher.cc:881-927) for a batch
+        of keyframes (FRUSTUM_POINT_DTYPE records in, WINDOW_QUERY_DTYPE records out, radius -1 for a dropped point); see
+        orbx_fuse_project_batch_device."""
+        _check(self._L.orbx_fuse_project_batch_device(
+            self._ctx, n, C.byref(params), C.c_void_p(d_poses), C.c_void_p(d_centres), C.c_void_p(d_points), q_cap,
+            C.c_void_p(d_nq), C.c_void_p(d_queries_out), C.c_void_p(d_n_projected), int(sync)), self._ctx)
+
     def fuse_search_batch_device(self, n, d_kps_un, kp_cap, d_cell_start, d_cell_idx, d_desc, d_u_right, min_x, min_y, inv_w,
                                  inv_h, d_queries, q_cap, d_nq, d_best_idx, d_best_dist, sync=True):
         """The search of ORBmatcher::Fuse(pKF, vpMapPoints, th) (src/ORBmatcher.cc:929-986) for a batch of keyframes and
@@ -545,6 +566,18 @@ class ORBextractor:
         ms = np.zeros(NUM_STAGES, np.float32)
         _check(self._L.orbx_get_stage_ms(self._ctx, _ptr(ms)), self._ctx)
         return {self._L.orbx_stage_name(i).decode(): float(ms[i]) for i in range(NUM_STAGES)}
+
+
+FRUSTUM_POINT_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("z", np.float32), ("nx", np.float32),
+                                ("ny", np.float32), ("nz", np.float32), ("min_dist", np.float32), ("max_dist", np.float32),
+                                ("flags", np.int32), ("desc", np.uint8, (32,))])
+assert FRUSTUM_POINT_DTYPE.itemsize == 68
+
+
+class FrustumParams(C.Structure):
+    """orbx_frustum_params."""
+    _fields_ = [(k, C.c_float) for k in ("fx", "fy", "cx", "cy", "mbf", "min_x", "max_x", "min_y", "max_y",
+                                         "view_cos_limit", "log_scale_factor", "th")]
 
 
 GUIDED_QUERY_DTYPE = np.dtype([("u", np.float32), ("v", np.float32), ("angle", np.float32), ("level", np.int32),

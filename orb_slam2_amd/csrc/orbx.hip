@@ -21,6 +21,7 @@
 #include "kernels_bow.hpp"
 #include "kernels_bowmatch.hpp"
 #include "kernels_initmatch.hpp"
+#include "kernels_project.hpp"
 #include "kernels_pyramid.hpp"
 #include "kernels_staging.hpp"
 #include "kernels_stereo.hpp"
@@ -1888,6 +1889,53 @@ extern "C" int orbx_search_for_initialization_batch_device(orbx_ctx* c, int n, c
     HIP_TRY(c, hipGetLastError());
     if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     return ORBX_OK;
+}
+
+// Shared body of the two map-point projections: mode 0 = Frame::isInFrustum, 1 = the tests of ORBmatcher::Fuse.
+static int project_points(orbx_ctx* c, int n, const orbx_frustum_params* p, const float* d_poses, const float* d_centres,
+                          const orbx_frustum_point* d_points, int q_cap, const int32_t* d_nq, void* d_out, int32_t* d_count,
+                          bool fuse, int sync) {
+    static_assert(sizeof(orbx_frustum_point) == 68, "point layout");
+    if (!c || !p || !d_poses || !d_centres || !d_points || !d_nq || !d_out || !d_count || n < 1 || q_cap < 1)
+        return ORBX_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    { int rc_ = join(c); if (rc_) return rc_; }
+    ProjectDev D;
+    D.points = d_points;
+    D.nq = d_nq;
+    D.poses = d_poses;
+    D.centres = d_centres;
+    D.out = d_out;
+    D.n_out = d_count;
+    D.q_cap = q_cap;
+    D.nlevels = c->prm.nlevels;
+    D.fx = p->fx; D.fy = p->fy; D.cx = p->cx; D.cy = p->cy; D.mbf = p->mbf;
+    D.min_x = p->min_x; D.max_x = p->max_x; D.min_y = p->min_y; D.max_y = p->max_y;
+    D.view_cos_limit = p->view_cos_limit;
+    D.log_scale_factor = p->log_scale_factor;
+    D.th = p->th;
+    for (int i = 0; i < ORBX_MAX_LEVELS; ++i) D.scale[i] = c->tab.scale[std::min(i, c->prm.nlevels - 1)];
+    HIP_TRY(c, hipMemsetAsync(d_count, 0, (size_t)n * sizeof(int32_t), c->stream));
+    const dim3 grid((q_cap + 255) / 256, n);
+    if (fuse) hipLaunchKernelGGL(k_project_points<true>, grid, dim3(256), 0, c->stream, D);
+    else hipLaunchKernelGGL(k_project_points<false>, grid, dim3(256), 0, c->stream, D);
+    HIP_TRY(c, hipGetLastError());
+    if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_is_in_frustum_batch_device(orbx_ctx* c, int n, const orbx_frustum_params* params, const float* d_poses,
+                                               const float* d_centres, const orbx_frustum_point* d_points, int q_cap,
+                                               const int32_t* d_nq, orbx_local_query* d_queries_out, int32_t* d_n_in_view,
+                                               int sync) {
+    return project_points(c, n, params, d_poses, d_centres, d_points, q_cap, d_nq, d_queries_out, d_n_in_view, false, sync);
+}
+
+extern "C" int orbx_fuse_project_batch_device(orbx_ctx* c, int n, const orbx_frustum_params* params, const float* d_poses,
+                                              const float* d_centres, const orbx_frustum_point* d_points, int q_cap,
+                                              const int32_t* d_nq, orbx_window_query* d_queries_out, int32_t* d_n_projected,
+                                              int sync) {
+    return project_points(c, n, params, d_poses, d_centres, d_points, q_cap, d_nq, d_queries_out, d_n_projected, true, sync);
 }
 
 extern "C" int orbx_rgbd_depth_batch_device(orbx_ctx* c, int n, const void* d_depth, int depth_is_f32, int width, int height,

@@ -644,3 +644,71 @@ def random_vocabulary(k, L, seed, scoring=0, weighting=0, prune=0.0, stop=0.0):
     weight[rng.random(n) < stop] = 0.0
     weight[0] = 0.0
     return Vocabulary(k, L, scoring, weighting, parent, is_leaf, desc, weight)
+
+
+def log_pinned(x):
+    """(float32) of the oracle's IEEE-only double logarithm of float32 values."""
+    L = lib()
+    L.orc_log_pinned.restype = C.c_double
+    L.orc_log_pinned.argtypes = [C.c_float]
+    return np.array([L.orc_log_pinned(float(v)) for v in np.asarray(x, np.float32).ravel()], np.float64)
+
+
+def _proj_args(Tcw, Ow, cam, bounds):
+    f4 = lambda a, k: (C.c_float * k)(*[float(v) for v in np.asarray(a, np.float32).ravel()])
+    return f4(Tcw, 12), f4(Ow, 3), f4(cam, 5), f4(bounds, 4)
+
+
+def is_in_frustum(Tcw, Ow, cam, bounds, view_cos_limit, log_scale_factor, n_levels, points):
+    """Frame::isInFrustum (reference src/Frame.cc:271-327) for the FRUSTUM_POINT_DTYPE-like records `points` (fields x, y, z,
+    nx, ny, nz, min_dist, max_dist, flags, desc) of one frame; points with flags bit 1 are skipped as
+    Tracking::SearchLocalPoints does (src/Tracking.cc:1343-1346).  Returns LOCAL_QUERY_DTYPE records and nToMatch."""
+    L = lib()
+    L.orc_is_in_frustum.argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                                                      C.c_float] + [C.c_void_p] * 5
+    T, O, cm, bd = _proj_args(Tcw, Ow, cam, bounds)
+    out = np.zeros(len(points), LOCAL_QUERY_DTYPE)
+    n_view = 0
+    for i, p in enumerate(points):
+        out[i]["desc"] = p["desc"]
+        out[i]["flags"] = (int(p["flags"]) & 1) | 2
+        if int(p["flags"]) & 2:
+            continue
+        P = (C.c_float * 3)(float(p["x"]), float(p["y"]), float(p["z"]))
+        Pn = (C.c_float * 3)(float(p["nx"]), float(p["ny"]), float(p["nz"]))
+        u, v, ur, vc = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+        lv = C.c_int()
+        ok = L.orc_is_in_frustum(T, O, cm, bd, float(view_cos_limit), float(log_scale_factor), int(n_levels), P, Pn,
+                                 float(p["min_dist"]), float(p["max_dist"]), C.byref(u), C.byref(v), C.byref(ur),
+                                 C.byref(lv), C.byref(vc))
+        if ok:
+            n_view += 1
+            out[i]["u"], out[i]["v"], out[i]["ur"] = u.value, v.value, ur.value
+            out[i]["level"], out[i]["view_cos"] = lv.value, vc.value
+            out[i]["flags"] = int(p["flags"]) & 1
+    return out, n_view
+
+
+def fuse_project(Tcw, Ow, cam, bounds, log_scale_factor, n_levels, scale_factors, th, points):
+    """The tests of ORBmatcher::Fuse in front of its search (reference src/ORBmatcher.cc:881-927) for the records `points`
+    of one keyframe; returns (u, v, ur, radius, level, ok) arrays, radius -1 where the point is dropped or skipped."""
+    L = lib()
+    L.orc_fuse_project.argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                                                     C.c_float, C.c_float] + [C.c_void_p] * 5
+    T, O, cm, bd = _proj_args(Tcw, Ow, cam, bounds)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    n = len(points)
+    uo, vo, uro = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    rad, lvl, okv = np.full(n, -1.0, np.float32), np.zeros(n, np.int32), np.zeros(n, bool)
+    for i, p in enumerate(points):
+        if int(p["flags"]) & 2:
+            continue
+        P = (C.c_float * 3)(float(p["x"]), float(p["y"]), float(p["z"]))
+        Pn = (C.c_float * 3)(float(p["nx"]), float(p["ny"]), float(p["nz"]))
+        u, v, ur, r = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+        lv = C.c_int()
+        if L.orc_fuse_project(T, O, cm, bd, float(log_scale_factor), int(n_levels), sf.ctypes.data, float(th), P, Pn,
+                              float(p["min_dist"]), float(p["max_dist"]), C.byref(u), C.byref(v), C.byref(ur), C.byref(r),
+                              C.byref(lv)):
+            uo[i], vo[i], uro[i], rad[i], lvl[i], okv[i] = u.value, v.value, ur.value, r.value, lv.value, True
+    return uo, vo, uro, rad, lvl, okv
