@@ -421,6 +421,20 @@ int orbx_search_guided_batch_device(orbx_ctx* ctx, int n, const orbx_kp* d_kps_u
                                     const int32_t* d_nq, int level_up, int max_dist, int check_orientation, int32_t* d_match,
                                     int32_t* d_query_match, int32_t* d_nmatches, int sync);
 
+/* Replaces the projections in front of the two guided searches, for a batch of frames / keyframes; the records written
+ * are the queries of orbx_search_guided_batch_device, radius = th * mvScaleFactors[level], flags 1 for
+ * a projected point and 3 for one that is skipped on input (flags bit 1) or dropped, angle = d_angles[f*q_cap + i]
+ * (pKF->mvKeysUn[i].angle for the rotation check; d_angles may be null: 0).  d_n_projected[f] counts the projected ones.
+ * relocalisation = 0: ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (reference
+ * src/ORBmatcher.cc:321-360), the tests of orbx_fuse_project_batch_device; d_poses / d_centres hold the pose taken out
+ * of the similarity (Rcw = sRcw / scw, tcw / scw, Ow: :299-303).  relocalisation = 1:
+ * ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (:1534-1563): no depth and no viewing
+ * test, the Frame's closed image bounds, the distance region, PredictScale. */
+int orbx_project_guided_batch_device(orbx_ctx* ctx, int n, const orbx_frustum_params* params, const float* d_poses,
+                                     const float* d_centres, const orbx_frustum_point* d_points, const float* d_angles,
+                                     int q_cap, const int32_t* d_nq, int relocalisation, orbx_guided_query* d_queries_out,
+                                     int32_t* d_n_projected, int sync);
+
 /* ---- descriptor consumer: matching by vocabulary node -------------------------------------
  * Replaces ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches) (reference
  * src/ORBmatcher.cc:159-290; called from Tracking::TrackReferenceKeyFrame, src/Tracking.cc:894, and

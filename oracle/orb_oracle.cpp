@@ -2141,3 +2141,30 @@ extern "C" int orc_fuse_project(const float Tcw[12], const float Ow[3], const fl
     *predicted_level = nPredictedLevel;
     return 1;
 }
+
+// The projection of ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (reference
+// src/ORBmatcher.cc:1534-1563) for one map point: no depth test and no viewing test.  Returns 0 when the point is dropped.
+extern "C" int orc_reloc_project(const float Tcw[12], const float Ow[3], const float cam[5], const float bounds[4],
+                                 float log_scale_factor, int n_levels, const float* scale_factors, float th, const float P[3],
+                                 float min_distance, float max_distance, float* u_out, float* v_out, float* radius,
+                                 int* predicted_level) {
+    const float none[3] = {0.0f, 0.0f, 0.0f};
+    const Projected g = project_point(Tcw, Ow, P, none);
+    const float xc = g.pc[0];
+    const float yc = g.pc[1];
+    const float invzc = (float)(1.0 / (double)g.pc[2]);  // :1539
+    const float u = cam[0] * xc * invzc + cam[2];
+    const float v = cam[1] * yc * invzc + cam[3];
+    if (u < bounds[0] || u > bounds[1]) return 0;  // :1544
+    if (v < bounds[2] || v > bounds[3]) return 0;
+    const float dist3D = g.dist;
+    const float maxDistance = 1.2f * max_distance;
+    const float minDistance = 0.8f * min_distance;
+    if (dist3D < minDistance || dist3D > maxDistance) return 0;  // :1557
+    const int nPredictedLevel = predict_scale(max_distance, dist3D, log_scale_factor, n_levels);
+    *radius = th * scale_factors[nPredictedLevel];  // :1563
+    *u_out = u;
+    *v_out = v;
+    *predicted_level = nPredictedLevel;
+    return 1;
+}

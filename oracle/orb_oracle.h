@@ -332,6 +332,12 @@ int orc_fuse_project(const float Tcw[12], const float Ow[3], const float cam[5],
                      const float Pn[3], float min_distance, float max_distance, float* u_out, float* v_out, float* ur_out,
                      float* radius, int* predicted_level);
 
+/* The projection of ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (reference
+ * src/ORBmatcher.cc:1534-1563). */
+int orc_reloc_project(const float Tcw[12], const float Ow[3], const float cam[5], const float bounds[4], float log_scale_factor,
+                      int n_levels, const float* scale_factors, float th, const float P[3], float min_distance,
+                      float max_distance, float* u_out, float* v_out, float* radius, int* predicted_level);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,7 +58,7 @@ EXPORTS = [
     "orbx_search_by_bow_keyframes_batch_device", "orbx_rgbd_depth_batch_device",
     "orbx_search_for_initialization_batch_device", "orbx_search_for_triangulation_batch_device",
     "orbx_fuse_search_batch_device", "orbx_search_guided_batch_device", "orbx_bow_score_l1_batch_device",
-    "orbx_is_in_frustum_batch_device", "orbx_fuse_project_batch_device",
+    "orbx_is_in_frustum_batch_device", "orbx_fuse_project_batch_device", "orbx_project_guided_batch_device",
 ]
 
 _lib = None
@@ -115,6 +115,7 @@ def load_library():
     L.orbx_bow_score_l1_batch_device.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32]
     L.orbx_is_in_frustum_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32]
     L.orbx_fuse_project_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32]
+    L.orbx_project_guided_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32]
     L.orbx_gray_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, i32, i32, vp, i32, C.c_size_t, i32]
     L.orbx_remap_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, vp, vp, i32, vp, i32, i32, i32,
                                           C.c_size_t, i32]
@@ -459,6 +460,16 @@ class ORBextractor:
         _check(self._L.orbx_fuse_project_batch_device(
             self._ctx, n, C.byref(params), C.c_void_p(d_poses), C.c_void_p(d_centres), C.c_void_p(d_points), q_cap,
             C.c_void_p(d_nq), C.c_void_p(d_queries_out), C.c_void_p(d_n_projected), int(sync)), self._ctx)
+
+    def project_guided_batch_device(self, n, params, d_poses, d_centres, d_points, d_angles, q_cap, d_nq, relocalisation,
+                                    d_queries_out, d_n_projected, sync=True):
+        """The projections in front of the guided searches (src/ORBmatcher.cc:321-360, or :1534-1563 with
+        relocalisation=True) for a batch of frames / keyframes: FRUSTUM_POINT_DTYPE records in, GUIDED_QUERY_DTYPE records
+        out; d_angles may be 0.  See orbx_project_guided_batch_device."""
+        _check(self._L.orbx_project_guided_batch_device(
+            self._ctx, n, C.byref(params), C.c_void_p(d_poses), C.c_void_p(d_centres), C.c_void_p(d_points),
+            C.c_void_p(d_angles), q_cap, C.c_void_p(d_nq), int(relocalisation), C.c_void_p(d_queries_out),
+            C.c_void_p(d_n_projected), int(sync)), self._ctx)
 
     def fuse_search_batch_device(self, n, d_kps_un, kp_cap, d_cell_start, d_cell_idx, d_desc, d_u_right, min_x, min_y, inv_w,
                                  inv_h, d_queries, q_cap, d_nq, d_best_idx, d_best_dist, sync=True):

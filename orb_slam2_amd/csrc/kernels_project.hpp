@@ -1,9 +1,11 @@
 // The projections in front of the windowed searches: Frame::isInFrustum (reference src/Frame.cc:271-327, called
 // per local map point from Tracking::SearchLocalPoints, src/Tracking.cc:1340-1353) with MapPoint::PredictScale
-// (src/MapPoint.cc:402-417), and the first half of ORBmatcher::Fuse(pKF, vpMapPoints, th)
-// (src/ORBmatcher.cc:881-927).  One thread per map point: 68 bytes in, 56 bytes out, which are the records the
-// local-map search and the Fuse search take, so a batch of poses and points goes from the map to matches
-// without a round trip through the host.
+// (src/MapPoint.cc:402-417); the first half of ORBmatcher::Fuse(pKF, vpMapPoints, th) (src/ORBmatcher.cc:881-927),
+// which Fuse(pKF, Scw, ...) (:1046-1086) and the loop closer's SearchByProjection(pKF, Scw, ...) (:321-360) repeat
+// with a pose taken out of a similarity; and the projection of the relocalisation's SearchByProjection
+// (:1534-1563).  One thread per map point: 68 bytes in, 56 bytes out, which are the records the local-map search,
+// the Fuse search and the guided search take, so a batch of poses and points goes from the map to matches without
+// a round trip through the host.
 //
 // Arithmetic as the reference's cv::Mat expressions evaluate it: Rcw * P + tcw in float, products summed left to
 // right; cv::norm and cv::Mat::dot of three floats accumulate in double; 1.0f / z, the pixel coordinates and
@@ -66,7 +68,8 @@ struct ProjectDev {
     const int32_t* nq;                 // [n]
     const float* poses;                // [n][12]: rows of [Rcw | tcw]
     const float* centres;              // [n][3]: mOw / Ow
-    void* out;                         // [n][q_cap] orbx_local_query or orbx_window_query
+    const float* angles;               // [n][q_cap] or null: the angle a guided record carries
+    void* out;                         // [n][q_cap] orbx_local_query, orbx_window_query or orbx_guided_query
     int32_t* n_out;                    // [n], zeroed before the launch
     int q_cap, nlevels;
     float fx, fy, cx, cy, mbf, min_x, max_x, min_y, max_y;
@@ -74,13 +77,19 @@ struct ProjectDev {
     float scale[ORBX_MAX_LEVELS];
 };
 
-// grid = (ceil(q_cap / 256), frames), block = 256.  FUSE = false: Frame::isInFrustum, out = orbx_local_query
-// (flags bit 1 set for a point that is skipped or out of view).  FUSE = true: ORBmatcher.cc:881-927, out =
-// orbx_window_query (radius -1 for a point that is skipped or fails a test: its window is empty).
+enum : int {
+    kProjFrustum = 0,  // Frame::isInFrustum -> orbx_local_query (flags bit 1 set for a point skipped or out of view)
+    kProjFuse = 1,     // ORBmatcher.cc:881-927 -> orbx_window_query (radius -1 for a point skipped or dropped: an empty window)
+    kProjLoop = 2,     // ORBmatcher.cc:321-360, the same tests -> orbx_guided_query (flags 1, or 3 for a point skipped or dropped)
+    kProjReloc = 3     // ORBmatcher.cc:1534-1563: no depth and no viewing test, the Frame's closed bounds -> orbx_guided_query
+};
+
+// grid = (ceil(q_cap / 256), frames), block = 256.
 // Every lane reads and writes its own record; staging the records through LDS for dword-consecutive global
 // accesses measured slower (0.048 against 0.041 ms for 512 x 2000 points): the lines are shared in the cache.
-template <bool FUSE>
+template <int MODE>
 __global__ __launch_bounds__(256) void k_project_points(ProjectDev D) {
+    constexpr bool FUSE = MODE == kProjFuse || MODE == kProjLoop;  // the arithmetic of ORBmatcher.cc:885-921
     __shared__ float s_scale[ORBX_MAX_LEVELS];
     const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     if (threadIdx.x < ORBX_MAX_LEVELS) s_scale[threadIdx.x] = D.scale[threadIdx.x];
@@ -101,13 +110,14 @@ __global__ __launch_bounds__(256) void k_project_points(ProjectDev D) {
             const float t = __fadd_rn(__fadd_rn(__fmul_rn(T[4 * r], pt.x), __fmul_rn(T[4 * r + 1], pt.y)), __fmul_rn(T[4 * r + 2], pt.z));
             pc[r] = __fadd_rn(t, T[4 * r + 3]);
         }
-        if (pc[2] < 0.0f) in_view = false;  // Frame.cc:285, ORBmatcher.cc:885
+        if (MODE != kProjReloc && pc[2] < 0.0f) in_view = false;  // Frame.cc:285, ORBmatcher.cc:885
+        // ORBmatcher.cc:1539 and :1056 divide in double and narrow: the same float (53 >= 2 * 24 + 2 bits)
         const float invz = __fdiv_rn(1.0f, pc[2]);
         if (FUSE) {  // ORBmatcher.cc:888-897, KeyFrame::IsInImage (src/KeyFrame.cc:616-619)
             u = __fadd_rn(__fmul_rn(D.fx, __fmul_rn(pc[0], invz)), D.cx);
             v = __fadd_rn(__fmul_rn(D.fy, __fmul_rn(pc[1], invz)), D.cy);
             if (!(u >= D.min_x && u < D.max_x && v >= D.min_y && v < D.max_y)) in_view = false;
-        } else {  // Frame.cc:289-296
+        } else {  // Frame.cc:289-296, ORBmatcher.cc:1541-1547
             u = __fadd_rn(__fmul_rn(__fmul_rn(D.fx, pc[0]), invz), D.cx);
             v = __fadd_rn(__fmul_rn(__fmul_rn(D.fy, pc[1]), invz), D.cy);
             if (u < D.min_x || u > D.max_x) in_view = false;
@@ -126,12 +136,22 @@ __global__ __launch_bounds__(256) void k_project_points(ProjectDev D) {
         dot = __dadd_rn(dot, __dmul_rn((double)po[2], (double)pt.nz));
         if (FUSE) {
             if (dot < __dmul_rn(0.5, (double)dist)) in_view = false;  // ORBmatcher.cc:921
-        } else {
+        } else if (MODE == kProjFrustum) {
             view_cos = (float)__ddiv_rn(dot, (double)dist);  // Frame.cc:310
             if (view_cos < D.view_cos_limit) in_view = false;
         }
         if (in_view) level = predict_scale(pt.max_dist, dist, D.log_scale_factor, D.nlevels);
-        if (FUSE) {
+        if (MODE == kProjLoop || MODE == kProjReloc) {
+            orbx_guided_query q;
+            q.u = in_view ? u : 0.0f;
+            q.v = in_view ? v : 0.0f;
+            q.angle = D.angles ? D.angles[at] : 0.0f;
+            q.level = level;
+            q.radius = in_view ? __fmul_rn(D.th, s_scale[level]) : -1.0f;  // ORBmatcher.cc:360, :1563
+            q.flags = in_view ? 1 : 3;
+            memcpy(q.desc, pt.desc, 32);
+            reinterpret_cast<orbx_guided_query*>(D.out)[at] = q;
+        } else if (MODE == kProjFuse) {
             orbx_window_query q;
             q.u = in_view ? u : 0.0f;
             q.v = in_view ? v : 0.0f;

@@ -1891,10 +1891,10 @@ extern "C" int orbx_search_for_initialization_batch_device(orbx_ctx* c, int n, c
     return ORBX_OK;
 }
 
-// Shared body of the two map-point projections: mode 0 = Frame::isInFrustum, 1 = the tests of ORBmatcher::Fuse.
+// Shared body of the map-point projections (mode: kProjFrustum .. kProjReloc).
 static int project_points(orbx_ctx* c, int n, const orbx_frustum_params* p, const float* d_poses, const float* d_centres,
-                          const orbx_frustum_point* d_points, int q_cap, const int32_t* d_nq, void* d_out, int32_t* d_count,
-                          bool fuse, int sync) {
+                          const orbx_frustum_point* d_points, const float* d_angles, int q_cap, const int32_t* d_nq,
+                          void* d_out, int32_t* d_count, int mode, int sync) {
     static_assert(sizeof(orbx_frustum_point) == 68, "point layout");
     if (!c || !p || !d_poses || !d_centres || !d_points || !d_nq || !d_out || !d_count || n < 1 || q_cap < 1)
         return ORBX_E_INVALID;
@@ -1905,6 +1905,7 @@ static int project_points(orbx_ctx* c, int n, const orbx_frustum_params* p, cons
     D.nq = d_nq;
     D.poses = d_poses;
     D.centres = d_centres;
+    D.angles = d_angles;
     D.out = d_out;
     D.n_out = d_count;
     D.q_cap = q_cap;
@@ -1917,8 +1918,12 @@ static int project_points(orbx_ctx* c, int n, const orbx_frustum_params* p, cons
     for (int i = 0; i < ORBX_MAX_LEVELS; ++i) D.scale[i] = c->tab.scale[std::min(i, c->prm.nlevels - 1)];
     HIP_TRY(c, hipMemsetAsync(d_count, 0, (size_t)n * sizeof(int32_t), c->stream));
     const dim3 grid((q_cap + 255) / 256, n);
-    if (fuse) hipLaunchKernelGGL(k_project_points<true>, grid, dim3(256), 0, c->stream, D);
-    else hipLaunchKernelGGL(k_project_points<false>, grid, dim3(256), 0, c->stream, D);
+    switch (mode) {
+        case kProjFrustum: hipLaunchKernelGGL(k_project_points<kProjFrustum>, grid, dim3(256), 0, c->stream, D); break;
+        case kProjFuse: hipLaunchKernelGGL(k_project_points<kProjFuse>, grid, dim3(256), 0, c->stream, D); break;
+        case kProjLoop: hipLaunchKernelGGL(k_project_points<kProjLoop>, grid, dim3(256), 0, c->stream, D); break;
+        default: hipLaunchKernelGGL(k_project_points<kProjReloc>, grid, dim3(256), 0, c->stream, D); break;
+    }
     HIP_TRY(c, hipGetLastError());
     if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     return ORBX_OK;
@@ -1928,14 +1933,24 @@ extern "C" int orbx_is_in_frustum_batch_device(orbx_ctx* c, int n, const orbx_fr
                                                const float* d_centres, const orbx_frustum_point* d_points, int q_cap,
                                                const int32_t* d_nq, orbx_local_query* d_queries_out, int32_t* d_n_in_view,
                                                int sync) {
-    return project_points(c, n, params, d_poses, d_centres, d_points, q_cap, d_nq, d_queries_out, d_n_in_view, false, sync);
+    return project_points(c, n, params, d_poses, d_centres, d_points, nullptr, q_cap, d_nq, d_queries_out, d_n_in_view,
+                          kProjFrustum, sync);
 }
 
 extern "C" int orbx_fuse_project_batch_device(orbx_ctx* c, int n, const orbx_frustum_params* params, const float* d_poses,
                                               const float* d_centres, const orbx_frustum_point* d_points, int q_cap,
                                               const int32_t* d_nq, orbx_window_query* d_queries_out, int32_t* d_n_projected,
                                               int sync) {
-    return project_points(c, n, params, d_poses, d_centres, d_points, q_cap, d_nq, d_queries_out, d_n_projected, true, sync);
+    return project_points(c, n, params, d_poses, d_centres, d_points, nullptr, q_cap, d_nq, d_queries_out, d_n_projected,
+                          kProjFuse, sync);
+}
+
+extern "C" int orbx_project_guided_batch_device(orbx_ctx* c, int n, const orbx_frustum_params* params, const float* d_poses,
+                                                const float* d_centres, const orbx_frustum_point* d_points,
+                                                const float* d_angles, int q_cap, const int32_t* d_nq, int relocalisation,
+                                                orbx_guided_query* d_queries_out, int32_t* d_n_projected, int sync) {
+    return project_points(c, n, params, d_poses, d_centres, d_points, d_angles, q_cap, d_nq, d_queries_out, d_n_projected,
+                          relocalisation ? kProjReloc : kProjLoop, sync);
 }
 
 extern "C" int orbx_rgbd_depth_batch_device(orbx_ctx* c, int n, const void* d_depth, int depth_is_f32, int width, int height,

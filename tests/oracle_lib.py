@@ -712,3 +712,36 @@ def fuse_project(Tcw, Ow, cam, bounds, log_scale_factor, n_levels, scale_factors
                               C.byref(lv)):
             uo[i], vo[i], uro[i], rad[i], lvl[i], okv[i] = u.value, v.value, ur.value, r.value, lv.value, True
     return uo, vo, uro, rad, lvl, okv
+
+
+def project_guided(Tcw, Ow, cam, bounds, log_scale_factor, n_levels, scale_factors, th, points, angles, relocalisation):
+    """The projections in front of the guided searches for the records `points` of one frame: relocalisation False =
+    ORBmatcher::SearchByProjection(pKF, Scw, ...) (reference src/ORBmatcher.cc:321-360, the tests of Fuse), True =
+    SearchByProjection(CurrentFrame, pKF, ...) (:1534-1563).  Returns GUIDED_QUERY_DTYPE records and the number projected."""
+    L = lib()
+    L.orc_reloc_project.argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_float,
+                                                      C.c_float] + [C.c_void_p] * 4
+    n = len(points)
+    out = np.zeros(n, GUIDED_QUERY_DTYPE)
+    out["desc"] = points["desc"]
+    out["angle"] = 0.0 if angles is None else np.asarray(angles, np.float32)
+    out["flags"], out["radius"] = 3, -1.0
+    if not relocalisation:
+        u, v, ur, rad, lvl, ok = fuse_project(Tcw, Ow, cam, bounds, log_scale_factor, n_levels, scale_factors, th, points)
+        out["u"], out["v"], out["radius"], out["level"] = u, v, rad, lvl
+        out["flags"] = np.where(ok, 1, 3)
+        return out, int(ok.sum())
+    T, O, cm, bd = _proj_args(Tcw, Ow, cam, bounds)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    count = 0
+    for i, p in enumerate(points):
+        if int(p["flags"]) & 2:
+            continue
+        P = (C.c_float * 3)(float(p["x"]), float(p["y"]), float(p["z"]))
+        u, v, r = C.c_float(), C.c_float(), C.c_float()
+        lv = C.c_int()
+        if L.orc_reloc_project(T, O, cm, bd, float(log_scale_factor), int(n_levels), sf.ctypes.data, float(th), P,
+                               float(p["min_dist"]), float(p["max_dist"]), C.byref(u), C.byref(v), C.byref(r), C.byref(lv)):
+            out[i]["u"], out[i]["v"], out[i]["radius"], out[i]["level"], out[i]["flags"] = u.value, v.value, r.value, lv.value, 1
+            count += 1
+    return out, count

@@ -1,7 +1,8 @@
 """GPU parity of the map-point projections -- Frame::isInFrustum with MapPoint::PredictScale (reference
 src/Frame.cc:271-327, src/MapPoint.cc:402-417) and the tests in front of the search of ORBmatcher::Fuse
 (src/ORBmatcher.cc:881-927) -- against the CPU oracle, bit for bit in every field, and the two device chains they
-feed: projection -> local-map search, projection -> Fuse search."""
+feed: projection -> local-map search, projection -> Fuse search; and the projections of the relocalisation's and the
+loop closer's SearchByProjection (src/ORBmatcher.cc:1534-1563, :321-360) -> guided search."""
 import numpy as np
 import pytest
 
@@ -226,6 +227,69 @@ def test_fuse_projection_then_fuse_search(oracle):
     assert found > 0.2 * counts.sum()
     ex.close()
     for a in list(d.values()) + [d_pts, d_nq, d_pose, d_ow, d_q, d_np, d_bi, d_bd]:
+        a.free()
+
+
+@pytest.mark.parametrize("relocalisation,th,max_dist,check", [(True, 10.0, 100, True), (False, 4.0, 50, False)])
+def test_guided_projection_then_guided_search(oracle, relocalisation, th, max_dist, check):
+    n = 2
+    ex, cap, d, grid = _extract(n, 93)
+    rng = np.random.default_rng(7 + relocalisation)
+    counts = d["n"].to_host()
+    un = d["un"].to_host().reshape(n, cap * 28).view(oa.KP_DTYPE).reshape(n, cap)
+    desc, cs, ci = d["desc"].to_host(), d["cs"].to_host(), d["ci"].to_host()
+    extra = 200
+    q_cap = cap + extra
+    points = np.zeros((n, q_cap), oa.FRUSTUM_POINT_DTYPE)
+    angles = np.zeros((n, q_cap), np.float32)
+    nq, poses, centres = np.zeros(n, np.int32), np.zeros((n, 12), np.float32), np.zeros((n, 3), np.float32)
+    for f in range(n):
+        T, Ow = _pose(rng)
+        poses[f], centres[f] = T.ravel(), Ow
+        k = int(counts[f])
+        pts = np.concatenate([_points_from_keypoints(rng, T, Ow, un[f, :k], desc[f, :k], NL), _edge_points(rng, T, Ow, extra)])
+        ang = np.concatenate([(un[f, :k]["angle"] + rng.normal(0, 3, k)) % 360, rng.uniform(0, 360, extra)]).astype(np.float32)
+        order = rng.permutation(len(pts))
+        nq[f] = len(pts)
+        points[f, :len(pts)], angles[f, :len(pts)] = pts[order], ang[order]
+    d_pts = DeviceArray.from_host(points.view(np.uint8).reshape(n, q_cap * 68))
+    d_ang = DeviceArray.from_host(angles)
+    d_nq, d_pose, d_ow = DeviceArray.from_host(nq), DeviceArray.from_host(poses), DeviceArray.from_host(centres)
+    d_q = DeviceArray((n, q_cap, 56), np.uint8, fill_byte=0x77)
+    d_np = DeviceArray((n,), np.int32, fill_byte=0x55)
+    prm = _params(0.5, th)
+    ex.project_guided_batch_device(n, prm, d_pose.ptr, d_ow.ptr, d_pts.ptr, d_ang.ptr, q_cap, d_nq.ptr, relocalisation, d_q.ptr,
+                                   d_np.ptr, sync=True)
+    got = d_q.to_host().reshape(n, q_cap * 56).view(oa.GUIDED_QUERY_DTYPE).reshape(n, q_cap)
+    npj = d_np.to_host()
+    want = []
+    for f in range(n):
+        w, cnt = oracle.project_guided(poses[f], centres[f], CAM, BOUNDS, prm.log_scale_factor, NL, ex.GetScaleFactors(), th,
+                                       points[f, :nq[f]], angles[f, :nq[f]], relocalisation)
+        want.append(w)
+        assert npj[f] == cnt and cnt > 0.3 * counts[f], (f, npj[f], cnt)
+        assert _same_bits(got[f, :nq[f]], w, ("u", "v", "angle", "level", "radius", "flags", "desc")) is None, f
+    # behind the camera: kept by the relocalisation's projection only
+    Tz = poses.reshape(n, 3, 4)
+    behind = sum(int(((Tz[f, 2, :3] * np.stack([points[f]["x"], points[f]["y"], points[f]["z"]], 1)).sum(1) + Tz[f, 2, 3] < 0)
+                     [:nq[f]][want[f]["flags"] == 1].sum()) for f in range(n))
+    assert (behind > 0) == bool(relocalisation)
+    # the records are the queries of the guided search
+    d_match, d_qm = DeviceArray((n, cap), np.int32, fill_byte=0x55), DeviceArray((n, q_cap), np.int32, fill_byte=0x55)
+    d_nm = DeviceArray((n,), np.int32, fill_byte=0x55)
+    level_up = 1 if relocalisation else 0
+    ex.search_guided_batch_device(n, d["un"].ptr, cap, d["cs"].ptr, d["ci"].ptr, d["desc"].ptr, 0, grid[0], grid[1], grid[2], grid[3],
+                                  d_q.ptr, q_cap, d_nq.ptr, level_up, max_dist, check, d_match.ptr, d_qm.ptr, d_nm.ptr, sync=True)
+    match, qm, nm = d_match.to_host(), d_qm.to_host(), d_nm.to_host()
+    for f in range(n):
+        k = int(counts[f])
+        xy = np.stack([un[f, :k]["x"], un[f, :k]["y"]], 1)
+        on, om, oqm = oracle.search_guided(xy, un[f, :k]["octave"], un[f, :k]["angle"], desc[f, :k], None, cs[f], ci[f, :k], grid[0],
+                                           grid[1], grid[2], grid[3], want[f], level_up, max_dist, check)
+        assert nm[f] == on and on > 0.15 * k, (f, nm[f], on, k)
+        assert (qm[f, :nq[f]] == oqm).all() and (match[f, :k] == om).all(), f
+    ex.close()
+    for a in list(d.values()) + [d_pts, d_ang, d_nq, d_pose, d_ow, d_q, d_np, d_match, d_qm, d_nm]:
         a.free()
 
 

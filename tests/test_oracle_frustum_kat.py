@@ -112,3 +112,32 @@ def test_predicted_level():
     # the Fuse record: u, v, ur as :892-899
     u, v, ur, rad, lvl, ok = fuse(pt(1.0, -0.5, 4.0, max_dist=4.2))
     assert (u, v, ur) == (445.0, 177.5, 435.0)
+
+
+def reloc(p, T=IDENT, Ow=(0, 0, 0), th=10.0):
+    out, n = oracle_lib.project_guided(T, Ow, CAM, BOUNDS, LOG12, 8, SCALE, th, p, None, True)
+    return out[0], n
+
+
+def test_relocalisation_projection_has_no_depth_and_no_viewing_test():
+    # src/ORBmatcher.cc:1534-1563: bounds closed, distance region, PredictScale, radius = th * scale[level]
+    q, n = reloc(pt(1.0, -0.5, 4.0, max_dist=8.0))
+    assert n == 1 and (q["u"], q["v"], q["flags"], q["level"]) == (445.0, 177.5, 1, 4)   # ratio 2 / ... dist = 4.153
+    assert q["radius"] == np.float32(10.0) * SCALE[4]
+    # a point behind the camera projects through the centre and is kept (there is no "PcZ < 0" here) ...
+    q, n = reloc(pt(0.2, 0.1, -2.0, max_dist=4.0))
+    assert n == 1 and (q["u"], q["v"]) == (270.0, 215.0)
+    # ... and so is one seen from behind its normal
+    assert reloc(pt(0, 0, 2.0, normal=(0, 0, -1), max_dist=2.0))[1] == 1
+    # the loop closer's projection (:321-360) drops both
+    loop = lambda p: oracle_lib.project_guided(IDENT, (0, 0, 0), CAM, BOUNDS, LOG12, 8, SCALE, 10.0, p, None, False)
+    assert loop(pt(0.2, 0.1, -2.0, max_dist=4.0))[1] == 0 and loop(pt(0, 0, 2.0, normal=(0, 0, -1), max_dist=2.0))[1] == 0
+    out, n = loop(pt(1.0, -0.5, 4.0, max_dist=8.0))
+    assert n == 1 and (out[0]["u"], out[0]["v"], out[0]["flags"], out[0]["level"]) == (445.0, 177.5, 1, 4)
+    # u == mnMaxX: inside for the Frame's bounds, outside for KeyFrame::IsInImage
+    edge = pt(0.64, 0, 1.0, normal=(0.5390, 0, 0.8423), max_dist=2.0)
+    assert reloc(edge)[1] == 1 and loop(edge)[1] == 0
+    # outside the distance region, skipped on input
+    assert reloc(pt(0, 0, 3.0, min_dist=0.1, max_dist=2.49))[1] == 0
+    q, n = reloc(pt(0, 0, 2.0, flags=2))
+    assert n == 0 and (q["flags"], q["radius"]) == (3, -1.0)
