@@ -366,6 +366,7 @@ int orbx_search_local_map_batch_device(orbx_ctx* ctx, int n, const orbx_kp* d_kp
  * orbx_fuse_project_batch_device replaces the tests in front of the search of ORBmatcher::Fuse(pKF, vpMapPoints, th)
  * (src/ORBmatcher.cc:881-927; KeyFrame::IsInImage, src/KeyFrame.cc:616-619): the same steps with that function's
  * arithmetic (x / z first, half-open image bounds, PO . Pn >= 0.5 * dist in double), d_centres = pKF->GetCameraCenter().
+ * Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) applies the same tests (:1046-1086) to the pose taken out of Scw (:1023-1027).
  * The records are the queries of orbx_fuse_search_batch_device: u, v, ur, radius = th * mvScaleFactors[level],
  * levels level - 1 .. level; a point that is skipped on input (flags bit 1: NULL, isBad() or IsInKeyFrame(pKF)) or
  * fails a test gets radius -1, an empty window, so its result is "no match".  d_n_projected[f] counts the others.
@@ -397,9 +398,9 @@ int orbx_fuse_project_batch_device(orbx_ctx* ctx, int n, const orbx_frustum_para
 /* Replaces the matching loops of ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th,
  * ORBdist) (reference src/ORBmatcher.cc:1509-1636; Tracking::Relocalization, src/Tracking.cc:1654 and :1670) and of
  * ORBmatcher::SearchByProjection(KeyFrame* pKF, Scw, vpPoints, vpMatched, th) (:290-403; LoopClosing::ComputeSim3,
- * src/LoopClosing.cc:378) for a batch of frames / keyframes.  The caller projects the map points (:1534-1563, :321-360: pose,
- * image bounds, distance invariance, viewing angle, PredictScale) and passes one record per point, in the reference's
- * order, with flags bit 1 set for a point the reference skips and bit 0 set otherwise.  Each point searches its
+ * src/LoopClosing.cc:378) for a batch of frames / keyframes.  The map points come projected (:1534-1563, :321-360: pose,
+ * image bounds, distance invariance, viewing angle, PredictScale -- orbx_project_guided_batch_device below does it on
+ * the device), one record per point, in the reference's order, with flags bit 1 set for a point the reference skips and bit 0 set otherwise.  Each point searches its
  * window on levels predicted - 1 .. predicted + level_up (1 for the first function, 0 for the second) among the
  * features that hold no map point -- d_taken before the call (mvpMapPoints[i] / vpMatched[i] != NULL), and those an
  * earlier point of this call took -- and takes the most similar one when its distance is <= max_dist (ORBdist;
