@@ -395,6 +395,18 @@ int orbx_fuse_project_batch_device(orbx_ctx* ctx, int n, const orbx_frustum_para
                                    const float* d_centres, const orbx_frustum_point* d_points, int q_cap,
                                    const int32_t* d_nq, orbx_window_query* d_queries_out, int32_t* d_n_projected, int sync);
 
+/* Replaces the projection of either direction of ORBmatcher::SearchBySim3 (reference src/ORBmatcher.cc:1195-1226 and
+ * :1275-1306) for a batch of keyframe pairs: the map points of one keyframe go through that keyframe's pose and the
+ * similarity between the cameras, d_poses[f*24 ..] = rows of [R1w | t1w], then rows of [sR21 | t21] (:1156-1158; the
+ * other direction passes [R2w | t2w] and [sR12 | t12]); depth not negative, KeyFrame::IsInImage of the target keyframe,
+ * the distance region and PredictScale on the length of the camera-frame point (:1216), no viewing test.  The records
+ * are window queries as orbx_fuse_project_batch_device writes them (radius -1 for a point skipped on input -- NULL,
+ * isBad() or already matched -- or dropped); the search is orbx_search_window_batch_device with d_u_right = d_taken =
+ * null and the caller's bestDist <= TH_HIGH.  The normals of the points, mbf and view_cos_limit are not read. */
+int orbx_sim3_project_batch_device(orbx_ctx* ctx, int n, const orbx_frustum_params* params, const float* d_poses,
+                                   const orbx_frustum_point* d_points, int q_cap, const int32_t* d_nq,
+                                   orbx_window_query* d_queries_out, int32_t* d_n_projected, int sync);
+
 /* Replaces the matching loops of ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th,
  * ORBdist) (reference src/ORBmatcher.cc:1509-1636; Tracking::Relocalization, src/Tracking.cc:1654 and :1670) and of
  * ORBmatcher::SearchByProjection(KeyFrame* pKF, Scw, vpPoints, vpMatched, th) (:290-403; LoopClosing::ComputeSim3,

@@ -2168,3 +2168,43 @@ extern "C" int orc_reloc_project(const float Tcw[12], const float Ow[3], const f
     *predicted_level = nPredictedLevel;
     return 1;
 }
+
+// The projection of one direction of ORBmatcher::SearchBySim3 (reference src/ORBmatcher.cc:1195-1226) for one map
+// point: T1w = [R1w | t1w], S21 = [sR21 | t21].  Returns 0 when the point is dropped.
+extern "C" int orc_sim3_project(const float T1w[12], const float S21[12], const float cam[5], const float bounds[4],
+                                float log_scale_factor, int n_levels, const float* scale_factors, float th, const float P[3],
+                                float min_distance, float max_distance, float* u_out, float* v_out, float* radius,
+                                int* predicted_level) {
+    float c1[3], c2[3];
+    for (int k = 0; k < 3; k++) {  // p3Dc1 = R1w * p3Dw + t1w (:1196)
+        float acc = T1w[4 * k] * P[0];
+        acc = acc + T1w[4 * k + 1] * P[1];
+        acc = acc + T1w[4 * k + 2] * P[2];
+        c1[k] = acc + T1w[4 * k + 3];
+    }
+    for (int k = 0; k < 3; k++) {  // p3Dc2 = sR21 * p3Dc1 + t21 (:1197)
+        float acc = S21[4 * k] * c1[0];
+        acc = acc + S21[4 * k + 1] * c1[1];
+        acc = acc + S21[4 * k + 2] * c1[2];
+        c2[k] = acc + S21[4 * k + 3];
+    }
+    if (c2[2] < 0.0) return 0;  // :1200
+    const float invz = (float)(1.0 / (double)c2[2]);
+    const float x = c2[0] * invz;
+    const float y = c2[1] * invz;
+    const float u = cam[0] * x + cam[2];
+    const float v = cam[1] * y + cam[3];
+    if (!(u >= bounds[0] && u < bounds[1] && v >= bounds[2] && v < bounds[3])) return 0;  // pKF2->IsInImage
+    double n2 = 0.0;
+    for (int k = 0; k < 3; k++) n2 += (double)c2[k] * (double)c2[k];
+    const float dist3D = (float)std::sqrt(n2);  // cv::norm(p3Dc2) (:1216)
+    const float maxDistance = 1.2f * max_distance;
+    const float minDistance = 0.8f * min_distance;
+    if (dist3D < minDistance || dist3D > maxDistance) return 0;  // :1219
+    const int nPredictedLevel = predict_scale(max_distance, dist3D, log_scale_factor, n_levels);
+    *radius = th * scale_factors[nPredictedLevel];  // :1226
+    *u_out = u;
+    *v_out = v;
+    *predicted_level = nPredictedLevel;
+    return 1;
+}

@@ -338,6 +338,11 @@ int orc_reloc_project(const float Tcw[12], const float Ow[3], const float cam[5]
                       int n_levels, const float* scale_factors, float th, const float P[3], float min_distance,
                       float max_distance, float* u_out, float* v_out, float* radius, int* predicted_level);
 
+/* The projection of one direction of ORBmatcher::SearchBySim3 (reference src/ORBmatcher.cc:1195-1226). */
+int orc_sim3_project(const float T1w[12], const float S21[12], const float cam[5], const float bounds[4], float log_scale_factor,
+                     int n_levels, const float* scale_factors, float th, const float P[3], float min_distance,
+                     float max_distance, float* u_out, float* v_out, float* radius, int* predicted_level);
+
 #ifdef __cplusplus
 }
 #endif

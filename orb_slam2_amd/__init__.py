@@ -59,6 +59,7 @@ EXPORTS = [
     "orbx_search_for_initialization_batch_device", "orbx_search_for_triangulation_batch_device",
     "orbx_fuse_search_batch_device", "orbx_search_guided_batch_device", "orbx_bow_score_l1_batch_device",
     "orbx_is_in_frustum_batch_device", "orbx_fuse_project_batch_device", "orbx_project_guided_batch_device",
+    "orbx_sim3_project_batch_device",
 ]
 
 _lib = None
@@ -116,6 +117,7 @@ def load_library():
     L.orbx_is_in_frustum_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32]
     L.orbx_fuse_project_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32]
     L.orbx_project_guided_batch_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32]
+    L.orbx_sim3_project_batch_device.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp, i32]
     L.orbx_gray_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, i32, i32, vp, i32, C.c_size_t, i32]
     L.orbx_remap_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, vp, vp, i32, vp, i32, i32, i32,
                                           C.c_size_t, i32]
@@ -470,6 +472,14 @@ class ORBextractor:
             self._ctx, n, C.byref(params), C.c_void_p(d_poses), C.c_void_p(d_centres), C.c_void_p(d_points),
             C.c_void_p(d_angles), q_cap, C.c_void_p(d_nq), int(relocalisation), C.c_void_p(d_queries_out),
             C.c_void_p(d_n_projected), int(sync)), self._ctx)
+
+    def sim3_project_batch_device(self, n, params, d_poses, d_points, q_cap, d_nq, d_queries_out, d_n_projected, sync=True):
+        """The projection of one direction of ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1195-1226) for a batch of keyframe
+        pairs: d_poses holds [R1w | t1w] and [sR21 | t21] per pair (24 floats), FRUSTUM_POINT_DTYPE records in,
+        WINDOW_QUERY_DTYPE records out.  See orbx_sim3_project_batch_device."""
+        _check(self._L.orbx_sim3_project_batch_device(
+            self._ctx, n, C.byref(params), C.c_void_p(d_poses), C.c_void_p(d_points), q_cap, C.c_void_p(d_nq),
+            C.c_void_p(d_queries_out), C.c_void_p(d_n_projected), int(sync)), self._ctx)
 
     def fuse_search_batch_device(self, n, d_kps_un, kp_cap, d_cell_start, d_cell_idx, d_desc, d_u_right, min_x, min_y, inv_w,
                                  inv_h, d_queries, q_cap, d_nq, d_best_idx, d_best_dist, sync=True):

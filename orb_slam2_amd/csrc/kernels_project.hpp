@@ -3,7 +3,7 @@
 // (src/MapPoint.cc:402-417); the first half of ORBmatcher::Fuse(pKF, vpMapPoints, th) (src/ORBmatcher.cc:881-927),
 // which Fuse(pKF, Scw, ...) (:1046-1086) and the loop closer's SearchByProjection(pKF, Scw, ...) (:321-360) repeat
 // with a pose taken out of a similarity; and the projection of the relocalisation's SearchByProjection
-// (:1534-1563).  One thread per map point: 68 bytes in, 56 bytes out, which are the records the local-map search,
+// (:1534-1563); and the two-step transform of SearchBySim3 (:1195-1226, :1275-1306).  One thread per map point: 68 bytes in, 56 bytes out, which are the records the local-map search,
 // the Fuse search and the guided search take, so a batch of poses and points goes from the map to matches without
 // a round trip through the host.
 //
@@ -66,8 +66,8 @@ __device__ __forceinline__ int predict_scale(float max_dist, float dist, float l
 struct ProjectDev {
     const orbx_frustum_point* points;  // [n][q_cap]
     const int32_t* nq;                 // [n]
-    const float* poses;                // [n][12]: rows of [Rcw | tcw]
-    const float* centres;              // [n][3]: mOw / Ow
+    const float* poses;                // [n][12]: rows of [Rcw | tcw]; kProjSim3: [n][24], [R1w | t1w] then [sR21 | t21]
+    const float* centres;              // [n][3]: mOw / Ow (not read by kProjSim3)
     const float* angles;               // [n][q_cap] or null: the angle a guided record carries
     void* out;                         // [n][q_cap] orbx_local_query, orbx_window_query or orbx_guided_query
     int32_t* n_out;                    // [n], zeroed before the launch
@@ -81,7 +81,9 @@ enum : int {
     kProjFrustum = 0,  // Frame::isInFrustum -> orbx_local_query (flags bit 1 set for a point skipped or out of view)
     kProjFuse = 1,     // ORBmatcher.cc:881-927 -> orbx_window_query (radius -1 for a point skipped or dropped: an empty window)
     kProjLoop = 2,     // ORBmatcher.cc:321-360, the same tests -> orbx_guided_query (flags 1, or 3 for a point skipped or dropped)
-    kProjReloc = 3     // ORBmatcher.cc:1534-1563: no depth and no viewing test, the Frame's closed bounds -> orbx_guided_query
+    kProjReloc = 3,    // ORBmatcher.cc:1534-1563: no depth and no viewing test, the Frame's closed bounds -> orbx_guided_query
+    kProjSim3 = 4      // ORBmatcher.cc:1195-1226: through the first keyframe's pose, then the similarity between the cameras;
+                       // the distance is that of the camera-frame point, no viewing test -> orbx_window_query
 };
 
 // grid = (ceil(q_cap / 256), frames), block = 256.
@@ -89,7 +91,8 @@ enum : int {
 // accesses measured slower (0.048 against 0.041 ms for 512 x 2000 points): the lines are shared in the cache.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_project_points(ProjectDev D) {
-    constexpr bool FUSE = MODE == kProjFuse || MODE == kProjLoop;  // the arithmetic of ORBmatcher.cc:885-921
+    constexpr bool FUSE = MODE == kProjFuse || MODE == kProjLoop;  // the tests of ORBmatcher.cc:885-921
+    constexpr bool KF = FUSE || MODE == kProjSim3;                 // x / z first, KeyFrame::IsInImage
     __shared__ float s_scale[ORBX_MAX_LEVELS];
     const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     if (threadIdx.x < ORBX_MAX_LEVELS) s_scale[threadIdx.x] = D.scale[threadIdx.x];
@@ -99,8 +102,7 @@ __global__ __launch_bounds__(256) void k_project_points(ProjectDev D) {
     if (i < nq) {
         const size_t at = (size_t)f * D.q_cap + i;
         const orbx_frustum_point pt = D.points[at];
-        const float* T = D.poses + (size_t)f * 12;
-        const float* O = D.centres + (size_t)f * 3;
+        const float* T = D.poses + (size_t)f * (MODE == kProjSim3 ? 24 : 12);
         float u = 0.0f, v = 0.0f, ur = 0.0f, view_cos = 0.0f;
         int level = 0;
         in_view = !(pt.flags & 2);
@@ -110,10 +112,20 @@ __global__ __launch_bounds__(256) void k_project_points(ProjectDev D) {
             const float t = __fadd_rn(__fadd_rn(__fmul_rn(T[4 * r], pt.x), __fmul_rn(T[4 * r + 1], pt.y)), __fmul_rn(T[4 * r + 2], pt.z));
             pc[r] = __fadd_rn(t, T[4 * r + 3]);
         }
+        if (MODE == kProjSim3) {  // p3Dc2 = sR21 * p3Dc1 + t21 (:1197)
+            const float* S = T + 12;
+            float p2[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float t = __fadd_rn(__fadd_rn(__fmul_rn(S[4 * r], pc[0]), __fmul_rn(S[4 * r + 1], pc[1])), __fmul_rn(S[4 * r + 2], pc[2]));
+                p2[r] = __fadd_rn(t, S[4 * r + 3]);
+            }
+            pc[0] = p2[0], pc[1] = p2[1], pc[2] = p2[2];
+        }
         if (MODE != kProjReloc && pc[2] < 0.0f) in_view = false;  // Frame.cc:285, ORBmatcher.cc:885
         // ORBmatcher.cc:1539 and :1056 divide in double and narrow: the same float (53 >= 2 * 24 + 2 bits)
         const float invz = __fdiv_rn(1.0f, pc[2]);
-        if (FUSE) {  // ORBmatcher.cc:888-897, KeyFrame::IsInImage (src/KeyFrame.cc:616-619)
+        if (KF) {  // ORBmatcher.cc:888-897, KeyFrame::IsInImage (src/KeyFrame.cc:616-619)
             u = __fadd_rn(__fmul_rn(D.fx, __fmul_rn(pc[0], invz)), D.cx);
             v = __fadd_rn(__fmul_rn(D.fy, __fmul_rn(pc[1], invz)), D.cy);
             if (!(u >= D.min_x && u < D.max_x && v >= D.min_y && v < D.max_y)) in_view = false;
@@ -125,7 +137,11 @@ __global__ __launch_bounds__(256) void k_project_points(ProjectDev D) {
         }
         ur = __fsub_rn(u, __fmul_rn(D.mbf, invz));  // Frame.cc:321, ORBmatcher.cc:899
         const float max_d = __fmul_rn(1.2f, pt.max_dist), min_d = __fmul_rn(0.8f, pt.min_dist);  // MapPoint.cc:373-383
-        const float po[3] = {__fsub_rn(pt.x, O[0]), __fsub_rn(pt.y, O[1]), __fsub_rn(pt.z, O[2])};
+        float po[3] = {pc[0], pc[1], pc[2]};  // kProjSim3: cv::norm(p3Dc2) (:1216)
+        if (MODE != kProjSim3) {
+            const float* O = D.centres + (size_t)f * 3;
+            po[0] = __fsub_rn(pt.x, O[0]), po[1] = __fsub_rn(pt.y, O[1]), po[2] = __fsub_rn(pt.z, O[2]);
+        }
         double n2 = __dmul_rn((double)po[0], (double)po[0]);
         n2 = __dadd_rn(n2, __dmul_rn((double)po[1], (double)po[1]));
         n2 = __dadd_rn(n2, __dmul_rn((double)po[2], (double)po[2]));
@@ -151,7 +167,7 @@ __global__ __launch_bounds__(256) void k_project_points(ProjectDev D) {
             q.flags = in_view ? 1 : 3;
             memcpy(q.desc, pt.desc, 32);
             reinterpret_cast<orbx_guided_query*>(D.out)[at] = q;
-        } else if (MODE == kProjFuse) {
+        } else if (MODE == kProjFuse || MODE == kProjSim3) {
             orbx_window_query q;
             q.u = in_view ? u : 0.0f;
             q.v = in_view ? v : 0.0f;

@@ -1896,7 +1896,8 @@ static int project_points(orbx_ctx* c, int n, const orbx_frustum_params* p, cons
                           const orbx_frustum_point* d_points, const float* d_angles, int q_cap, const int32_t* d_nq,
                           void* d_out, int32_t* d_count, int mode, int sync) {
     static_assert(sizeof(orbx_frustum_point) == 68, "point layout");
-    if (!c || !p || !d_poses || !d_centres || !d_points || !d_nq || !d_out || !d_count || n < 1 || q_cap < 1)
+    if (!c || !p || !d_poses || (!d_centres && mode != kProjSim3) || !d_points || !d_nq || !d_out || !d_count || n < 1 ||
+        q_cap < 1)
         return ORBX_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->prm.device_id));
     { int rc_ = join(c); if (rc_) return rc_; }
@@ -1922,6 +1923,7 @@ static int project_points(orbx_ctx* c, int n, const orbx_frustum_params* p, cons
         case kProjFrustum: hipLaunchKernelGGL(k_project_points<kProjFrustum>, grid, dim3(256), 0, c->stream, D); break;
         case kProjFuse: hipLaunchKernelGGL(k_project_points<kProjFuse>, grid, dim3(256), 0, c->stream, D); break;
         case kProjLoop: hipLaunchKernelGGL(k_project_points<kProjLoop>, grid, dim3(256), 0, c->stream, D); break;
+        case kProjSim3: hipLaunchKernelGGL(k_project_points<kProjSim3>, grid, dim3(256), 0, c->stream, D); break;
         default: hipLaunchKernelGGL(k_project_points<kProjReloc>, grid, dim3(256), 0, c->stream, D); break;
     }
     HIP_TRY(c, hipGetLastError());
@@ -1943,6 +1945,13 @@ extern "C" int orbx_fuse_project_batch_device(orbx_ctx* c, int n, const orbx_fru
                                               int sync) {
     return project_points(c, n, params, d_poses, d_centres, d_points, nullptr, q_cap, d_nq, d_queries_out, d_n_projected,
                           kProjFuse, sync);
+}
+
+extern "C" int orbx_sim3_project_batch_device(orbx_ctx* c, int n, const orbx_frustum_params* params, const float* d_poses,
+                                              const orbx_frustum_point* d_points, int q_cap, const int32_t* d_nq,
+                                              orbx_window_query* d_queries_out, int32_t* d_n_projected, int sync) {
+    return project_points(c, n, params, d_poses, nullptr, d_points, nullptr, q_cap, d_nq, d_queries_out, d_n_projected, kProjSim3,
+                          sync);
 }
 
 extern "C" int orbx_project_guided_batch_device(orbx_ctx* c, int n, const orbx_frustum_params* params, const float* d_poses,

@@ -745,3 +745,27 @@ def project_guided(Tcw, Ow, cam, bounds, log_scale_factor, n_levels, scale_facto
             out[i]["u"], out[i]["v"], out[i]["radius"], out[i]["level"], out[i]["flags"] = u.value, v.value, r.value, lv.value, 1
             count += 1
     return out, count
+
+
+def sim3_project(T1w, S21, cam, bounds, log_scale_factor, n_levels, scale_factors, th, points):
+    """The projection of one direction of ORBmatcher::SearchBySim3 (reference src/ORBmatcher.cc:1195-1226) for the records
+    `points` of one keyframe pair; returns (u, v, radius, level, ok) arrays, radius -1 where the point is dropped or skipped."""
+    L = lib()
+    L.orc_sim3_project.argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_float,
+                                                     C.c_float] + [C.c_void_p] * 4
+    f4 = lambda a, k: (C.c_float * k)(*[float(v) for v in np.asarray(a, np.float32).ravel()])
+    T, S, cm, bd = f4(T1w, 12), f4(S21, 12), f4(cam, 5), f4(bounds, 4)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    n = len(points)
+    uo, vo = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    rad, lvl, okv = np.full(n, -1.0, np.float32), np.zeros(n, np.int32), np.zeros(n, bool)
+    for i, p in enumerate(points):
+        if int(p["flags"]) & 2:
+            continue
+        P = (C.c_float * 3)(float(p["x"]), float(p["y"]), float(p["z"]))
+        u, v, r = C.c_float(), C.c_float(), C.c_float()
+        lv = C.c_int()
+        if L.orc_sim3_project(T, S, cm, bd, float(log_scale_factor), int(n_levels), sf.ctypes.data, float(th), P,
+                              float(p["min_dist"]), float(p["max_dist"]), C.byref(u), C.byref(v), C.byref(r), C.byref(lv)):
+            uo[i], vo[i], rad[i], lvl[i], okv[i] = u.value, v.value, r.value, lv.value, True
+    return uo, vo, rad, lvl, okv

@@ -2,7 +2,8 @@
 src/Frame.cc:271-327, src/MapPoint.cc:402-417) and the tests in front of the search of ORBmatcher::Fuse
 (src/ORBmatcher.cc:881-927) -- against the CPU oracle, bit for bit in every field, and the two device chains they
 feed: projection -> local-map search, projection -> Fuse search; and the projections of the relocalisation's and the
-loop closer's SearchByProjection (src/ORBmatcher.cc:1534-1563, :321-360) -> guided search."""
+loop closer's SearchByProjection (src/ORBmatcher.cc:1534-1563, :321-360) -> guided search; SearchBySim3's projection
+(:1195-1226) -> window search."""
 import numpy as np
 import pytest
 
@@ -290,6 +291,78 @@ def test_guided_projection_then_guided_search(oracle, relocalisation, th, max_di
         assert (qm[f, :nq[f]] == oqm).all() and (match[f, :k] == om).all(), f
     ex.close()
     for a in list(d.values()) + [d_pts, d_ang, d_nq, d_pose, d_ow, d_q, d_np, d_match, d_qm, d_nm]:
+        a.free()
+
+
+def test_sim3_projection_then_window_search(oracle):
+    n = 2
+    ex, cap, d, grid = _extract(n, 94)
+    rng = np.random.default_rng(11)
+    counts = d["n"].to_host()
+    un = d["un"].to_host().reshape(n, cap * 28).view(oa.KP_DTYPE).reshape(n, cap)
+    desc, cs, ci = d["desc"].to_host(), d["cs"].to_host(), d["ci"].to_host()
+    extra, th = 200, 7.5
+    q_cap = cap + extra
+    points = np.zeros((n, q_cap), oa.FRUSTUM_POINT_DTYPE)
+    nq, poses = np.zeros(n, np.int32), np.zeros((n, 24), np.float32)
+    for f in range(n):
+        # camera 2 sees the points at pose T2 (where they project onto its keypoints); camera 1 and the similarity are
+        # chosen so that sR21 * (R1w P + t1w) + t21 is about R2w P + t2w with a scale drift of s
+        T2, Ow2 = _pose(rng)
+        T1, _ = _pose(rng, big=True)
+        s21 = 1.0 + 0.05 * f
+        R1, t1 = T1[:, :3].astype(np.float64), T1[:, 3].astype(np.float64)
+        R2, t2 = T2[:, :3].astype(np.float64), T2[:, 3].astype(np.float64)
+        R21 = R2 @ R1.T
+        S = np.concatenate([s21 * R21, (s21 * (t2 - R21 @ t1))[:, None]], 1).astype(np.float32)
+        poses[f, :12], poses[f, 12:] = T1.ravel(), S.ravel()
+        k = int(counts[f])
+        pts = _points_from_keypoints(rng, T2, Ow2, un[f, :k], desc[f, :k], NL)
+        pts["max_dist"] *= s21
+        pts["min_dist"] *= s21
+        pts = np.concatenate([pts, _edge_points(rng, T2, Ow2, extra)])
+        pts = pts[rng.permutation(len(pts))]
+        nq[f] = len(pts)
+        points[f, :len(pts)] = pts
+    d_pts = DeviceArray.from_host(points.view(np.uint8).reshape(n, q_cap * 68))
+    d_nq, d_pose = DeviceArray.from_host(nq), DeviceArray.from_host(poses)
+    d_q = DeviceArray((n, q_cap, 56), np.uint8, fill_byte=0x77)
+    d_np = DeviceArray((n,), np.int32, fill_byte=0x55)
+    prm = _params(0.5, th)
+    ex.sim3_project_batch_device(n, prm, d_pose.ptr, d_pts.ptr, q_cap, d_nq.ptr, d_q.ptr, d_np.ptr, sync=True)
+    got = d_q.to_host().reshape(n, q_cap * 56).view(oa.WINDOW_QUERY_DTYPE).reshape(n, q_cap)
+    npj = d_np.to_host()
+    wants = []
+    for f in range(n):
+        u, v, rad, lvl, ok = oracle.sim3_project(poses[f, :12], poses[f, 12:], CAM, BOUNDS, prm.log_scale_factor, NL,
+                                                 ex.GetScaleFactors(), th, points[f, :nq[f]])
+        wants.append((u, v, rad, lvl, ok))
+        g = got[f, :nq[f]]
+        assert npj[f] == ok.sum() and ok.sum() > 0.5 * counts[f], (f, npj[f], ok.sum())
+        assert ((g["radius"] == -1.0) == ~ok).all()
+        for name, w in (("u", u), ("v", v), ("radius", rad)):
+            assert (g[name][ok].view(np.uint32) == w[ok].view(np.uint32)).all(), (f, name)
+        assert (g["max_level"][ok] == lvl[ok]).all() and (g["min_level"][ok] == lvl[ok] - 1).all()
+        assert (g["desc"] == points[f, :nq[f]]["desc"]).all()
+    d_bi, d_bd = DeviceArray((n, q_cap), np.int32, fill_byte=0x55), DeviceArray((n, q_cap), np.int32, fill_byte=0x55)
+    ex.search_window_batch_device(n, d["un"].ptr, cap, d["cs"].ptr, d["ci"].ptr, d["desc"].ptr, 0, 0, grid[0], grid[1], grid[2],
+                                  grid[3], d_q.ptr, q_cap, d_nq.ptr, d_bi.ptr, d_bd.ptr, sync=True)
+    bi, bd = d_bi.to_host(), d_bd.to_host()
+    found = 0
+    for f in range(n):
+        k = int(counts[f])
+        xy = np.stack([un[f, :k]["x"], un[f, :k]["y"]], 1)
+        u, v, rad, lvl, ok = wants[f]
+        assert ((bi[f, :nq[f]][~ok] == -1) & (bd[f, :nq[f]][~ok] == 256)).all()
+        for i in np.flatnonzero(ok)[::2]:
+            idx, dist = oracle.search_window(xy, un[f, :k]["octave"], desc[f, :k], None, None, cs[f], ci[f, :k], grid[0], grid[1],
+                                             grid[2], grid[3], float(u[i]), float(v[i]), float(rad[i]), int(lvl[i]) - 1, int(lvl[i]),
+                                             0.0, points[f, i]["desc"])[:2]
+            assert (bi[f, i], bd[f, i]) == (idx, dist), (f, i)
+            found += idx >= 0 and dist <= 100
+    assert found > 0.15 * counts.sum()
+    ex.close()
+    for a in list(d.values()) + [d_pts, d_nq, d_pose, d_q, d_np, d_bi, d_bd]:
         a.free()
 
 

@@ -141,3 +141,22 @@ def test_relocalisation_projection_has_no_depth_and_no_viewing_test():
     assert reloc(pt(0, 0, 3.0, min_dist=0.1, max_dist=2.49))[1] == 0
     q, n = reloc(pt(0, 0, 2.0, flags=2))
     assert n == 0 and (q["flags"], q["radius"]) == (3, -1.0)
+
+
+def test_sim3_projection():
+    # src/ORBmatcher.cc:1195-1226: camera 1 at the origin, camera 2 = camera 1 scaled by 1/2 and shifted by (0.1, 0, 0)
+    S21 = np.array([[0.5, 0, 0, 0.1], [0, 0.5, 0, 0], [0, 0, 0.5, 0]], np.float32)
+    sim3 = lambda p, T=IDENT, S=S21, th=7.5: [a[0] for a in oracle_lib.sim3_project(T, S, CAM, BOUNDS, LOG12, 8, SCALE, th, p)]
+    # P = (1, -0.5, 4) -> camera 2: (0.6, -0.25, 2); u = 500 * 0.3 + 320, v = 500 * -0.125 + 240
+    u, v, rad, lvl, ok = sim3(pt(1.0, -0.5, 4.0, max_dist=4.0))
+    assert ok and (u, v) == (470.0, 177.5)
+    # the distance is the length of the camera-2 point, 2.103: ratio 1.902 -> level 4
+    assert lvl == 4 and rad == np.float32(7.5) * SCALE[4]
+    # depth in camera 2 decides, the normal does not; IsInImage's half-open bounds
+    assert not sim3(pt(0, 0, -1.0))[4]
+    assert sim3(pt(0, 0, 2.0, normal=(0, 0, -1), max_dist=1.0))[4]
+    assert not sim3(pt(1.08, 0, 2.0, max_dist=2.0))[4]            # x2 = 0.64, z2 = 1: u = 640
+    assert sim3(pt(1.0799, 0, 2.0, max_dist=2.0))[4]
+    # the distance region is tested on the camera-2 length: 1 for (0, 0, 2)
+    assert sim3(pt(0, 0, 2.0, min_dist=1.25, max_dist=5.0))[4] and not sim3(pt(0, 0, 2.0, min_dist=1.26, max_dist=5.0))[4]
+    assert not sim3(pt(0, 0, 2.0, max_dist=1.0, flags=2))[4]
