@@ -70,6 +70,12 @@ __device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(fast_i16x2, a), __builtin_bit_cast(fast_i16x2, b)));
 }
+__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) {  // wrapping, per 16-bit lane
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(fast_i16x2, a) - __builtin_bit_cast(fast_i16x2, b));
+}
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {  // wrapping, per 16-bit lane
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(fast_i16x2, a) + __builtin_bit_cast(fast_i16x2, b));
+}
 __device__ __forceinline__ int arc_max_pk(const uint32_t X[8]) {
     uint32_t m2[8], m4[8], m8[8];
 #pragma unroll

@@ -275,7 +275,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             const uint8_t* qr = ql + kStereoWinL;
             if (lane < 55) {
                 const int dc = (int)ql[5 * 16 + 5] - (int)qr[5 * 32 + s + 5];
-                uint32_t acc = 0;
+                // |(pa - cl) - (pb - cr)| = |pa - pb - dc| for two pixels per instruction: v_perm_b32 widens two
+                // bytes to the halves of a dword, packed 16-bit subtract / negate / maximum / add do the rest
+                // (7 instructions per pixel pair instead of 6 per pixel; v_sad_u32 would take one per pixel but
+                // issues at a quarter of the rate).  The twelfth pixel of a row is not part of the window: its
+                // halves are zero, and so is its half of dc.
+                const uint32_t dc2 = (uint32_t)(dc & 0xFFFF) * 0x00010001u, dc1 = (uint32_t)(dc & 0xFFFF);
+                uint32_t acc2 = 0;  // two partial sums, each at most 3 rows * 6 pixels * 510
                 for (int r = g; r < 11; r += 5) {
                     const uint4 av = *reinterpret_cast<const uint4*>(ql + r * 16);
                     const uint32_t* rq = reinterpret_cast<const uint32_t*>(qr + r * 32 + q4);
@@ -284,16 +290,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
                     const uint32_t b[3] = {__builtin_amdgcn_alignbyte(r1, r0, sh), __builtin_amdgcn_alignbyte(r2, r1, sh),
                                            __builtin_amdgcn_alignbyte(r3, r2, sh)};
 #pragma unroll
-                    for (int xx = 0; xx < 11; ++xx) {
-                        const int pa = (int)((a[xx >> 2] >> (8 * (xx & 3))) & 0xFFu);
-                        const int pb = (int)((b[xx >> 2] >> (8 * (xx & 3))) & 0xFFu);
-                        // |(pa - cl) - (pb - cr)|; v_sad_u32 would do it in one instruction but issues
-                        // at a quarter of the rate of sub/max
-                        const int t = pa - pb - dc;
-                        acc += (uint32_t)max(t, -t);
+                    for (int pp = 0; pp < 6; ++pp) {
+                        const uint32_t sel = pp == 5 ? 0x0C0C0C02u : (pp & 1) ? 0x0C030C02u : 0x0C010C00u;
+                        const uint32_t A = __builtin_amdgcn_perm(0u, a[pp >> 1], sel), Bq = __builtin_amdgcn_perm(0u, b[pp >> 1], sel);
+                        const uint32_t t = pk_sub_i16(pk_sub_i16(A, Bq), pp == 5 ? dc1 : dc2);
+                        acc2 = pk_add_u16(acc2, pk_max_i16(t, pk_sub_i16(0u, t)));
                     }
                 }
-                s_acc[wave][q][lane] = (uint16_t)acc;
+                s_acc[wave][q][lane] = (uint16_t)((acc2 & 0xFFFFu) + (acc2 >> 16));
             }
         }
     }
