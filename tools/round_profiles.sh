@@ -14,5 +14,7 @@ rm -rf $G/traffic_$TAG
 bash tools/pmc_multi.sh $TAG orbx > $G/${TAG}_pmc_sq.txt 2>&1
 python3 tools/valu_summary.py $G/${TAG}_valu.json $G/pmc_${TAG}_sq/pmc_counter_collection.csv $G/pmc_${TAG}_sq2/pmc_counter_collection.csv > $G/${TAG}_valu.log
 rm -rf $G/pmc_${TAG}_sq $G/pmc_${TAG}_sq2 $G/pmc_${TAG}_sq3 $G/pmc_${TAG}_sq*.txt
+# the bench line reads the counter summaries of the running sources from profiles/
+cp $G/${TAG}_traffic.json $G/${TAG}_valu.json profiles/
 timeout -k 10 900 python3 bench.py > $G/${TAG}_bench.json 2> $G/${TAG}_bench.err
 echo done
