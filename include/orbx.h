@@ -580,7 +580,10 @@ enum {
                                  coordinates, quadtree list order                             */
 };
 /* Reads an intermediate of the last extraction into dst (capacity cap_bytes); *n_bytes
- * receives the size.  No counterpart in the reference (its intermediates are locals). */
+ * receives the size.  No counterpart in the reference (its intermediates are locals).
+ * After an orbx_extract_batch call that ran in chunks (16 frames or more) the candidate and
+ * retained-point lists have been reused chunk by chunk: those two reads return ORBX_E_STATE;
+ * the blurred levels and the pyramid exist for every frame of the batch. */
 int orbx_debug_read(orbx_ctx* ctx, int what, int img_idx, int level, void* dst, size_t cap_bytes,
                     size_t* n_bytes);
 

@@ -122,6 +122,7 @@ struct orbx_ctx {
     // last batch (for read-backs and for the stereo stage)
     BatchDev B;
     bool have_last = false;
+    bool last_chunked = false;           // the last batch ran chunk by chunk: FAST and quadtree lists exist for its last chunks only
     const orbx_kp* last_kps = nullptr;   // where the last extraction left its results (device)
     const uint8_t* last_desc = nullptr;
     const int32_t* last_n = nullptr;
@@ -691,6 +692,7 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     if (prof) c->ev_valid = true;
     HIP_TRY(c, hipGetLastError());
     c->have_last = true;
+    c->last_chunked = false;
     c->last_kps = d_kps;
     c->last_desc = d_desc;
     c->last_n = d_n_out;
@@ -971,6 +973,7 @@ int extract_batch_pipelined(orbx_ctx* c, int n, const uint8_t* const* imgs, int 
     c->last_kps = d_kps;
     c->last_desc = d_desc;
     c->last_n = d_cnt;
+    c->last_chunked = nchunks > 1;
     return ORBX_OK;
 }
 
@@ -1057,6 +1060,7 @@ int extract_graph(orbx_ctx* c, const uint8_t* img, int width, int height, int st
     c->last_kp_cap = cap;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->have_last = true;
+    c->last_chunked = false;
     const uint8_t* o = (const uint8_t*)c->h_gout;
     int32_t k = 0;
     std::memcpy(&k, o + (size_t)cap * (sizeof(orbx_kp) + 32), 4);
@@ -2031,6 +2035,7 @@ extern "C" int orbx_debug_read(orbx_ctx* c, int what, int img_idx, int level, vo
     { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     const LevelDev& D = c->B.lv[level];
     const BatchDev& B = c->B;
+    if (what != ORBX_DBG_BLURRED && c->last_chunked) return ORBX_E_STATE;  // the lists were reused chunk by chunk
     if (what == ORBX_DBG_BLURRED) {
         *n_bytes = (size_t)D.w * D.h;
         if (cap_bytes < *n_bytes) return ORBX_E_CAPACITY;

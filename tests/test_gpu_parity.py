@@ -97,6 +97,8 @@ def test_pipelined_host_batch(oracle, monkeypatch):
     for i in range(n):                                 # every chunk, including the short last one
         okps, odesc = orc.extract(imgs[i])
         _check_final(res[i][0], res[i][1], okps, odesc)
+    with pytest.raises(oa.OrbxError):                  # the candidate lists were reused chunk by chunk
+        ex.debug_read(oa.DBG_CANDIDATES, 9, 0)
     orc.extract(imgs[9])                               # pyramid of a frame of the second chunk
     for l in range(nl):
         assert (ex.pyramid_level(9, l) == orc.level(l)).all()
