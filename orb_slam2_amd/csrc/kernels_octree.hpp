@@ -91,12 +91,22 @@ __host__ __device__ inline size_t oct_lds_bytes(int max_slots, int max_kp, int n
 
 // grid = (frames, nlevels), block = NT (256, or 1024 for levels of thousands of features), dynamic LDS = max
 // over levels of oct_lds_bytes.
-template <int NT>
+// GT (global tables): quotas whose tables do not fit the LDS (above about 2500 features per level) keep them in a
+// workspace in device memory instead, ws_stride bytes per (frame, level), dynamic LDS = 0.  The code is the same:
+// the tables are reached through pointers, the atomics become global atomics, and the barriers order the
+// workgroup's global accesses as they order its LDS accesses.  Slower, and only there so that such quotas run.
+template <int NT, bool GT>
 __global__ __launch_bounds__(NT) void k_octree(BatchDev B, const uint32_t* __restrict__ cand,
                                                 const uint32_t* __restrict__ ccount,
                                                 uint32_t* __restrict__ dense_pts, uint16_t* __restrict__ dense_node,
-                                                uint32_t* __restrict__ lvl_kps, int32_t* __restrict__ lvl_count) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
+                                                uint32_t* __restrict__ lvl_kps, int32_t* __restrict__ lvl_count,
+                                                uint8_t* __restrict__ ws, size_t ws_stride) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_lds[];
+    uint8_t* s_raw;
+    if constexpr (GT)
+        s_raw = ws + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * ws_stride;
+    else
+        s_raw = s_lds;
     __shared__ int s_wave4[NT / 64];
     __shared__ int s_i[8];  // 0: jcut, 1: nToExpand, 2: finished, 3: careful
 

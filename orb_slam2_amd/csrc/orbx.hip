@@ -112,6 +112,9 @@ struct orbx_ctx {
     DevBuf d_pyr[2], d_blur[2], d_lvl_kps[2], d_lvl_count[2];
     DevBuf d_cand[2], d_ccount[2];  // FAST output, alternating like the retained points (index kp_set)
     DevBuf d_dense_pts, d_dense_node;
+    DevBuf d_oct_ws;          // quadtree tables of quotas that do not fit the LDS (oct_global), per (frame, level)
+    bool oct_global = false;
+    size_t oct_ws_stride = 0;
     int arena_set = 0, kp_set = 0;            // sets of the last batch
     int arena_desc[2] = {-1, -1};             // descriptor event (index into ev_desc) last reading each arena set
     bool desc_pending[2] = {false, false};    // ev_desc[i] recorded and not yet joined
@@ -259,7 +262,7 @@ int set_geometry(orbx_ctx* c, int w, int h) {
         max_kp_level = std::max(max_kp_level, g.max_kp);
         oct_lds = std::max(oct_lds, oct_lds_bytes(g.max_slots, g.max_kp, g.n_cells));
     }
-    if (oct_lds > 160 * 1024 - 256) return ORBX_E_GEOMETRY;
+    const bool oct_global = oct_lds > 160 * 1024 - 256;  // the quadtree then keeps its tables in device memory
     for (LevelGeom& g : levels) {
         g.max_cand = g.n_cells * cell_cap;
         if (g.max_cand > 0xFFFFFF) return ORBX_E_GEOMETRY;  // the quadtree packs a candidate's index into 24 bits
@@ -357,7 +360,9 @@ int set_geometry(orbx_ctx* c, int w, int h) {
     c->dense_total = dense_total;
     c->kp_total = kp_total;
     c->max_kp_level = max_kp_level;
-    c->oct_lds = oct_lds;
+    c->oct_lds = oct_global ? 0 : oct_lds;
+    c->oct_global = oct_global;
+    c->oct_ws_stride = oct_global ? align_up(oct_lds, 256) : 0;
     c->cur_w = w;
     c->cur_h = h;
     c->have_last = false;
@@ -419,6 +424,7 @@ int ensure_arenas(orbx_ctx* c, int n, bool need_level0) {
         if ((rc = ensure(c, &c->d_ccount[k], (size_t)n * c->total_cells * 4))) return rc;
     }
     if ((rc = ensure(c, &c->d_dense_pts, (size_t)n * c->dense_total * 4))) return rc;
+    if (c->oct_global && (rc = ensure(c, &c->d_oct_ws, (size_t)n * c->tab.nlevels * c->oct_ws_stride))) return rc;
     if ((rc = ensure(c, &c->d_dense_node, (size_t)n * c->dense_total * 2))) return rc;
     return ORBX_OK;
 }
@@ -650,14 +656,19 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     // 1024 threads per (frame, level) when a level keeps more than a thousand features (the loops over the
     // points and the rank-by-counting of the nodes are then long) or when the batch is so small that the launch
     // leaves most of the GPU idle anyway (a single frame: the level's sweeps are the critical path), else 256
-    if (c->max_kp_level > kOctWideFrom || n * L <= kOctWideBelowBlocks)
-        hipLaunchKernelGGL(k_octree<1024>, dim3(n, L), dim3(1024), c->oct_lds, so, B, (const uint32_t*)c->d_cand[kp_set].p,
+    if (c->oct_global)
+        hipLaunchKernelGGL((k_octree<1024, true>), dim3(n, L), dim3(1024), 0, so, B, (const uint32_t*)c->d_cand[kp_set].p,
                            (const uint32_t*)c->d_ccount[kp_set].p, (uint32_t*)c->d_dense_pts.p, (uint16_t*)c->d_dense_node.p,
-                           (uint32_t*)c->d_lvl_kps[kp_set].p, (int32_t*)c->d_lvl_count[kp_set].p);
+                           (uint32_t*)c->d_lvl_kps[kp_set].p, (int32_t*)c->d_lvl_count[kp_set].p, (uint8_t*)c->d_oct_ws.p,
+                           c->oct_ws_stride);
+    else if (c->max_kp_level > kOctWideFrom || n * L <= kOctWideBelowBlocks)
+        hipLaunchKernelGGL((k_octree<1024, false>), dim3(n, L), dim3(1024), c->oct_lds, so, B, (const uint32_t*)c->d_cand[kp_set].p,
+                           (const uint32_t*)c->d_ccount[kp_set].p, (uint32_t*)c->d_dense_pts.p, (uint16_t*)c->d_dense_node.p,
+                           (uint32_t*)c->d_lvl_kps[kp_set].p, (int32_t*)c->d_lvl_count[kp_set].p, (uint8_t*)nullptr, (size_t)0);
     else
-        hipLaunchKernelGGL(k_octree<256>, dim3(n, L), dim3(256), c->oct_lds, so, B, (const uint32_t*)c->d_cand[kp_set].p,
+        hipLaunchKernelGGL((k_octree<256, false>), dim3(n, L), dim3(256), c->oct_lds, so, B, (const uint32_t*)c->d_cand[kp_set].p,
                            (const uint32_t*)c->d_ccount[kp_set].p, (uint32_t*)c->d_dense_pts.p, (uint16_t*)c->d_dense_node.p,
-                           (uint32_t*)c->d_lvl_kps[kp_set].p, (int32_t*)c->d_lvl_count[kp_set].p);
+                           (uint32_t*)c->d_lvl_kps[kp_set].p, (int32_t*)c->d_lvl_count[kp_set].p, (uint8_t*)nullptr, (size_t)0);
     if ((rc = mark(kEvOct1, so))) return rc;
     hipStream_t sd = st;  // stream of the descriptor stage
     if (overlap) {
@@ -1124,7 +1135,7 @@ extern "C" int orbx_create(const orbx_params* params, orbx_ctx** out) {
     c->ev_made = true;
     // every context sets the same limit, so a later context cannot lower what an earlier one relies on
     for (const void* fn : {reinterpret_cast<const void*>(k_fast_tiles<0>), reinterpret_cast<const void*>(k_fast_tiles<kFastFixedPitch>),
-                           reinterpret_cast<const void*>(k_octree<256>), reinterpret_cast<const void*>(k_octree<1024>),
+                           reinterpret_cast<const void*>(k_octree<256, false>), reinterpret_cast<const void*>(k_octree<1024, false>),
                            reinterpret_cast<const void*>(k_bow_vectors)})
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds) != hipSuccess)
             return fail(ORBX_E_HIP);
@@ -1166,7 +1177,7 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
     }
 #endif
     DevBuf* bufs[] = {&c->d_cells, &c->d_tiles, &c->d_pat, &c->d_pyr[0], &c->d_pyr[1], &c->d_blur[0], &c->d_blur[1],
-                      &c->d_cand[0], &c->d_cand[1], &c->d_ccount[0], &c->d_ccount[1], &c->d_dense_pts, &c->d_dense_node, &c->d_lvl_kps[0], &c->d_lvl_kps[1],
+                      &c->d_cand[0], &c->d_cand[1], &c->d_ccount[0], &c->d_ccount[1], &c->d_dense_pts, &c->d_dense_node, &c->d_oct_ws, &c->d_lvl_kps[0], &c->d_lvl_kps[1],
                       &c->d_lvl_count[0], &c->d_lvl_count[1], &c->d_out_kps,
                       &c->d_out_desc, &c->d_out_n, &c->d_stamps, &c->d_proj_minq, &c->d_proj_state, &c->d_proj_list, &c->d_proj_cache, &c->d_proj_ncache, &c->d_local_pick, &c->d_st_rows, &c->d_st_meta, &c->d_st_wmax,
                       &c->d_st_sad, &c->d_st_u, &c->d_st_depth};

@@ -340,6 +340,29 @@ def test_parameter_space(oracle, w, h, nf, scale, nl, ini, mn, cid):
     ex.close()
 
 
+@pytest.mark.parametrize("w,h,nf,nl,cid", [
+    (640, 480, 3000, 1, 21),       # one level that keeps 3000 features
+    (1168, 665, 6000, 2, 22),      # 3273 + 2727
+    (1500, 1100, 8000, 1, 23),     # the largest quota a level can have is 8189
+])
+def test_quotas_beyond_the_lds_tables(oracle, w, h, nf, nl, cid):
+    """A level whose quota is above about 2500 features does not fit the quadtree's LDS tables: the kernel then keeps
+    them in device memory (same code, global atomics).  Single frame and a batch of three."""
+    imgs = [synth.make_frame(w, h, cid, k) for k in range(3)]
+    ex = oa.ORBextractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=3)
+    orc = oracle.Oracle(nf, 1.2, nl, 20, 7)
+    kps, desc = ex(imgs[0])
+    okps, odesc = orc.extract(imgs[0])
+    _check_stages(ex, orc, imgs[0])
+    _check_final(kps, desc, okps, odesc)
+    assert len(kps) > 0.7 * nf
+    res = ex.extract_batch(imgs)
+    for k in range(3):
+        okps, odesc = orc.extract(imgs[k])
+        _check_final(res[k][0], res[k][1], okps, odesc)
+    ex.close()
+
+
 def test_resize_tiled_kernel(oracle, monkeypatch):
     """The pyramid has three resize kernels: the streaming one (taps of four columns within eight source
     bytes), the LDS-tiled one for everything else, and for a launch of one small frame the one that produces

@@ -20,16 +20,16 @@ import orb_slam2_amd as oa  # noqa: E402
 from orb_slam2_amd import synth  # noqa: E402
 
 
-def random_case(rng):
+def random_case(rng, max_w=1600, max_h=1200):
     scale = float(rng.choice([1.1, 1.2, 1.2, 1.2, 1.25, 1.3, 1.5, 2.0]))
     nlev = int(rng.integers(1, 11))
     # every level must keep 62 px on each side, and the image must not be much taller than wide
     lo = int(np.ceil(64 * scale ** (nlev - 1))) + 2
-    if lo > 1500:
+    if lo > min(max_w, max_h) - 100:
         nlev = 3
         lo = int(np.ceil(64 * scale ** (nlev - 1))) + 2
-    w = int(rng.integers(lo, max(lo + 1, 1600)))
-    h = int(rng.integers(lo, max(lo + 1, min(1200, int(1.4 * w)))))
+    w = int(rng.integers(lo, max(lo + 1, max_w)))
+    h = int(rng.integers(lo, max(lo + 1, min(max_h, int(1.4 * w)))))
     nf = int(rng.choice([30, 100, 300, 500, 1000, 1500, 2000, 3000, 6000]))
     ini = int(rng.integers(5, 60))
     mn = int(rng.integers(1, ini + 1))
@@ -92,11 +92,13 @@ def main():
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--batch", type=int, default=9, help="frames per batch call (8 or more: frame-major launches; 16 or more: the chunked host path)")
+    ap.add_argument("--max-width", type=int, default=1600)
+    ap.add_argument("--max-height", type=int, default=1200)
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     bad, t0, nkp = 0, time.time(), 0
     for i in range(a.cases):
-        c = random_case(rng)
+        c = random_case(rng, a.max_width, a.max_height)
         try:
             ex = oa.ORBextractor(c["nf"], c["scale"], c["nlev"], c["ini"], c["mn"], max_width=c["w"], max_height=c["h"],
                                  max_batch=a.batch)
