@@ -584,7 +584,11 @@ __global__ __launch_bounds__(256) void k_fast_tiles(BatchDev B, const TileDesc* 
     if (frame >= B.nframes) return;
     const TileDesc td = tiles[tile_i];
     const LevelDev& L = B.lv[td.level];
+#ifdef ORBX_DIAG_FAST_READS_FRAME0  // diagnostic build: every frame's tiles are staged from frame 0 (cache hits)
+    const uint8_t* img = L.img;
+#else
     const uint8_t* img = L.img + (uint64_t)frame * L.plane;
+#endif
     const int wd = td.wd, hd = td.hd, nc = td.nc, w_cell = td.w_cell;
     const int TP = TPC ? TPC : fast_tile_pitch(wd);
     const int SP = fast_plane_pitch(wd, nc);

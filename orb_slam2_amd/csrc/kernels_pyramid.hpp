@@ -406,7 +406,11 @@ __global__ __launch_bounds__(256) void k_blur7_all(BatchDev B, int frame_major) 
     const LevelDev& L = B.lv[level];
     const int blk = blk_all - B.blur_first[level];
     const int w = L.w, h = L.h, spitch = L.pitch, dpitch = L.bpitch;
+#ifdef ORBX_DIAG_BLUR_READS_FRAME0  // diagnostic build: every frame's blur reads frame 0 (cache hits), an upper bound on what sharing a staged tile could save
+    const uint8_t* S8 = L.img;
+#else
     const uint8_t* S8 = L.img + (uint64_t)frame * L.plane;
+#endif
     uint8_t* D8 = L.blur + (uint64_t)frame * L.bplane;
     const int tid = threadIdx.x;
     // streaming lanes store dwords x0 in [4, last_full]; edge blocks own [0,4) and [xs, w)
