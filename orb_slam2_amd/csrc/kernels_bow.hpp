@@ -268,8 +268,8 @@ struct WindowDev {
 // on_cand(i2, dist, key, keypoint) runs for every candidate that passes the filters.
 template <int CTRL>
 __device__ __forceinline__ void window_min_dpp(uint32_t& k, int& v) {
-    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k, CTRL, 0xF, 0xF, false);
-    const int w = __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k, CTRL, 0xF, 0xF, true);
+    const int w = __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
     const bool take = o < k;
     k = take ? o : k;
     v = take ? w : v;
@@ -844,10 +844,10 @@ __device__ __forceinline__ void top2_merge(uint32_t& k1, uint32_t& k2, int& v1, 
 // trip).  Every lane of the row must be active.
 template <int CTRL>
 __device__ __forceinline__ void top2_merge_dpp(uint32_t& k1, uint32_t& k2, int& v1, int& v2) {
-    const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k1, CTRL, 0xF, 0xF, false);
-    const uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k2, CTRL, 0xF, 0xF, false);
-    const int w1 = __builtin_amdgcn_update_dpp(0, v1, CTRL, 0xF, 0xF, false);
-    const int w2 = __builtin_amdgcn_update_dpp(0, v2, CTRL, 0xF, 0xF, false);
+    const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k1, CTRL, 0xF, 0xF, true);
+    const uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k2, CTRL, 0xF, 0xF, true);
+    const int w1 = __builtin_amdgcn_update_dpp(0, v1, CTRL, 0xF, 0xF, true);
+    const int w2 = __builtin_amdgcn_update_dpp(0, v2, CTRL, 0xF, 0xF, true);
     top2_merge(k1, k2, v1, v2, o1, o2, w1, w2);
 }
 

@@ -50,8 +50,8 @@ __device__ __forceinline__ void bow_top2_merge(uint32_t& k1, uint32_t& k2, uint3
 
 template <int CTRL>
 __device__ __forceinline__ void bow_top2_merge_dpp(uint32_t& k1, uint32_t& k2) {
-    const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k1, CTRL, 0xF, 0xF, false);
-    const uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k2, CTRL, 0xF, 0xF, false);
+    const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k1, CTRL, 0xF, 0xF, true);
+    const uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k2, CTRL, 0xF, 0xF, true);
     bow_top2_merge(k1, k2, o1, o2);
 }
 

@@ -368,8 +368,8 @@ __device__ __forceinline__ void blur_stream(const __amdgpu_buffer_rsrc_t rs, con
 #pragma unroll
     for (int r = 0; r < kBlurRows + 6; ++r) {
         const uint32_t C = qC[r % kBlurPF];
-        const uint32_t Lw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x138, 0xF, 0xF, false);  // lane - 1
-        const uint32_t R = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x130, 0xF, 0xF, false);   // lane + 1
+        const uint32_t Lw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x138, 0xF, 0xF, true);  // lane - 1
+        const uint32_t R = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x130, 0xF, 0xF, true);   // lane + 1
         if (r + kBlurPF < kBlurRows + 6) {
             const int vo = INNER ? (int)(vbase + (uint32_t)((r + kBlurPF) * spitch)) : reflect101(min(y0 + r + kBlurPF - 3, h + 2), h) * spitch + vcol;
             qC[r % kBlurPF] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0, 0);

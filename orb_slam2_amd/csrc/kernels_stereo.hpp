@@ -60,9 +60,9 @@ constexpr int kStereoKpPerBlock = 32;  // left keypoints per workgroup of k_ster
 // Minimum over an aligned group of eight lanes, left in all of them, through DPP (lane pairs, quads, the two quads
 // of a half row): no LDS round trip.  The eight lanes of a group are active together.
 __device__ __forceinline__ uint32_t min_over_8(uint32_t v) {
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false));  // row_half_mirror
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));  // row_half_mirror
     return v;
 }
 
