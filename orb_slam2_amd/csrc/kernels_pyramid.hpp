@@ -174,7 +174,6 @@ __global__ __launch_bounds__(256) void k_resize_rows(const uint8_t* __restrict__
     const bool live = item < n_frames * nd;
     const int f = live ? item / nd : 0;
     const int x0 = live ? 4 * (item - f * nd) : 0;
-    const int nvalid = min(4, dw - x0);
     ResizeTap tx[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) tx[k] = xt[min(x0 + k, dw - 1)];
@@ -226,14 +225,10 @@ __global__ __launch_bounds__(256) void k_resize_rows(const uint8_t* __restrict__
                     const uint32_t t = mul_hi_u24(b0, Xp[px]) + mul_hi_u24(b1, X[px]) + 2u;
                     out |= (t >> 2) << (8 * px);
                 }
-                if (live) {
-                    uint8_t* d = D + (uint64_t)y * dpitch;
-                    if (nvalid == 4) {
-                        *reinterpret_cast<uint32_t*>(d) = out;
-                    } else {
-                        for (int px = 0; px < nvalid; ++px) d[px] = (uint8_t)(out >> (8 * px));
-                    }
-                }
+                // the last dword of a row is stored whole: the row pitch is a multiple of 64, the columns beyond the
+                // level's width are padding that nothing reads (they receive the last column's value), and a byte
+                // store is a partial write of its own to the memory system
+                if (live) *reinterpret_cast<uint32_t*>(D + (uint64_t)y * dpitch) = out;
                 ++y;
                 t_cur = t_nxt;
                 t_nxt = resize_row_tap(yt, min(y + 1, dh - 1));
@@ -437,12 +432,20 @@ __global__ __launch_bounds__(256) void k_blur7_all(BatchDev B, int frame_major) 
         __syncthreads();
         if (tid < kBlurEdgeRows && yb + tid < h) {
             uint8_t* drow = D8 + (uint64_t)(yb + tid) * dpitch;
+            // the columns leave as dwords (rows and xs are dword-aligned): a byte store is a partial write of its own
+            // to the memory system
+            uint32_t packed[3] = {0, 0, 0};
             for (int e = 0; e < 4 + nright; ++e) {
                 uint32_t acc = 0;
 #pragma unroll
                 for (int j = 0; j < 7; ++j) acc += gauss_tap(j) * s_sum[tid + j][e];
-                drow[e < 4 ? e : xs + (e - 4)] = (uint8_t)min(255u, (acc + 32768u) >> 16);
+                packed[e >> 2] |= min(255u, (acc + 32768u) >> 16) << (8 * (e & 3));
             }
+            // (the dwords that reach beyond the image end in the row's padding: the pitch is a multiple of 64 and
+            // nothing reads the padding)
+            *reinterpret_cast<uint32_t*>(drow) = packed[0];
+            *reinterpret_cast<uint32_t*>(drow + xs) = packed[1];
+            if (nright > 4) *reinterpret_cast<uint32_t*>(drow + xs + 4) = packed[2];
         }
         return;
     }
