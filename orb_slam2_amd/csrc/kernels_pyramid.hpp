@@ -418,13 +418,29 @@ __global__ __launch_bounds__(256) void k_blur7_all(BatchDev B, int frame_major) 
         const int nright = w - xs;  // 3..6
         if (tid < kBlurEdgeRows + 6) {
             const int yy = reflect101(min(yb + tid - 3, h + 2), h);
-            const uint8_t* row = S8 + (uint64_t)yy * spitch;
+            // Everything the row contributes comes in with five dword loads issued together: columns 0..7 and
+            // xs-4..xs+7 (the lanes of a wave are rows a pitch apart, so every load instruction touches 64 cache
+            // lines: loading the 70 taps byte by byte cost more than the whole streaming part of a level's rim).
+            const uint32_t* row = reinterpret_cast<const uint32_t*>(S8 + (uint64_t)yy * spitch);
+            const uint32_t L0 = row[0], L1 = row[1];
+            const int xr = (xs >> 2) - 1;                           // dword index of column xs - 4
+            const uint32_t R0 = row[xr], R1 = row[xr + 1];
+            const uint32_t R2 = nright > 4 ? row[xr + 2] : 0u;      // columns xs+4.. exist only then
+            auto left = [&](int x) -> uint32_t {                     // columns 0..7
+                return ((x < 4 ? L0 : L1) >> (8 * (x & 3))) & 0xFFu;
+            };
+            auto right = [&](int x) -> uint32_t {                    // columns xs-4 .. w-1
+                const int o = x - (xs - 4);
+                return ((o < 4 ? R0 : o < 8 ? R1 : R2) >> (8 * (o & 3))) & 0xFFu;
+            };
             for (int e = 0; e < 10; ++e) {
-                const int x = e < 4 ? e : xs + (e - 4);
                 uint32_t rs = 0;
-                if (e < 4 + nright) {
+                if (e < 4) {
 #pragma unroll
-                    for (int t = 0; t < 7; ++t) rs += gauss_tap(t) * row[reflect101(x + t - 3, w)];
+                    for (int t = 0; t < 7; ++t) rs += gauss_tap(t) * left(reflect101(e + t - 3, w));
+                } else if (e < 4 + nright) {
+#pragma unroll
+                    for (int t = 0; t < 7; ++t) rs += gauss_tap(t) * right(reflect101(xs + (e - 4) + t - 3, w));
                 }
                 s_sum[tid][e] = (uint16_t)rs;
             }
