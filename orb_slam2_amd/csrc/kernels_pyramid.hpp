@@ -308,7 +308,6 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // blocks of a frame, which share halo rows and neighbour columns, then meet in one L2.
 constexpr int kBlurRows = 32;
 constexpr int kBlurPF = 8;
-constexpr int kBlurEdgeRows = 128;  // output rows per edge block
 constexpr int kBlurItems = 4 * 62;  // (row tile, dword column) pairs per streaming block: 62 per wave
 
 // Column pass for one pixel at row r.  pr[j % 6] holds the row sums of rows (j, j+1) packed as
@@ -341,33 +340,64 @@ __host__ __device__ inline int blur_main_blocks(int w, int h) {
     const int nd = (w + 3) >> 2, nty = (h + kBlurRows - 1) / kBlurRows;
     return (nd * nty + kBlurItems - 1) / kBlurItems;
 }
-__host__ __device__ inline int blur_edge_blocks(int h) { return (h + kBlurEdgeRows - 1) / kBlurEdgeRows; }
+
+
+// Selector of a v_perm_b32 that builds the dword of columns tb .. tb+3 of a row of width w, reflected at the image's
+// sides (BORDER_REFLECT_101), from two dwords: `hi` holds columns hb .. hb+3 (selector values 4..7), `lo` columns
+// lb .. lb+3 (values 0..3).  Columns no tap can reach (more than 3 outside the image) get byte 0 of `lo`.
+__device__ __forceinline__ uint32_t blur_rim_selector(int tb, int hb, int lb, int w) {
+    uint32_t sel = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int col = tb + k;
+        uint32_t idx = 0;
+        if (col >= -3 && col <= w + 2) {
+            const int rc = reflect101(col, w);
+            idx = (rc >= hb && rc < hb + 4) ? (uint32_t)(4 + rc - hb) : (uint32_t)((rc - lb) & 3);
+        }
+        sel |= idx << (8 * k);
+    }
+    return sel;
+}
 
 // The streaming part of k_blur7_all for one lane: walks down the lane's row tile.  INNER: every source row of
 // the tile lies inside the image (see the call).
-template <bool INNER>
+// RIM: some lane of the wave owns a dword column at the left or right rim of the image; its neighbour dwords (and, in
+// the last column, the bytes beyond the image's width) are then rebuilt from the reflected columns by byte
+// permutations with per-lane selectors (blur_rim_selectors; identity in every other lane).
+template <bool INNER, bool RIM>
 __device__ __forceinline__ void blur_stream(const __amdgpu_buffer_rsrc_t rs, const __amdgpu_buffer_rsrc_t rd, int y0, int h,
-                                            int spitch, int dpitch, int vcol, int x0, bool store_ok) {
+                                            int spitch, int dpitch, int vcol, int x0, bool store_ok, uint32_t sel_l,
+                                            uint32_t sel_c, uint32_t sel_r, bool last_col) {
     const int kOut = 0x7FFFFFF0;
+    // loads in flight: two fewer where both the row reflection and the rim selectors are live, to stay within 64 registers
+    constexpr int PF = (!INNER && RIM) ? kBlurPF - 2 : kBlurPF;
     // INNER: offsets of the tile's first source row and first output dword (unsigned: a lane with nothing to
     // load or store starts at kOut and stays out of the buffer's range)
     const uint32_t vbase = (uint32_t)((y0 - 3) * spitch) + (uint32_t)vcol;
     const uint32_t sbase = store_ok ? (uint32_t)(y0 * dpitch + x0) : (uint32_t)kOut;
-    uint32_t qC[kBlurPF];
+    uint32_t qC[PF];
 #pragma unroll
-    for (int r = 0; r < kBlurPF; ++r) {
+    for (int r = 0; r < PF; ++r) {
         const int vo = INNER ? (int)(vbase + (uint32_t)(r * spitch)) : reflect101(min(y0 + r - 3, h + 2), h) * spitch + vcol;
         qC[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0, 0);
     }
     uint32_t pr[6][4], wp[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < kBlurRows + 6; ++r) {
-        const uint32_t C = qC[r % kBlurPF];
-        const uint32_t Lw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x138, 0xF, 0xF, true);  // lane - 1
-        const uint32_t R = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x130, 0xF, 0xF, true);   // lane + 1
-        if (r + kBlurPF < kBlurRows + 6) {
-            const int vo = INNER ? (int)(vbase + (uint32_t)((r + kBlurPF) * spitch)) : reflect101(min(y0 + r + kBlurPF - 3, h + 2), h) * spitch + vcol;
-            qC[r % kBlurPF] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0, 0);
+        uint32_t C = qC[r % PF];
+        uint32_t Lw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x138, 0xF, 0xF, true);  // lane - 1
+        uint32_t R = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)C, 0x130, 0xF, 0xF, true);   // lane + 1
+        if (RIM) {
+            const uint32_t z = last_col ? Lw : R;  // the last column's right neighbour is made of its own and its left dword
+            const uint32_t l2 = __builtin_amdgcn_perm(C, Lw, sel_l), c2 = __builtin_amdgcn_perm(C, Lw, sel_c);
+            R = __builtin_amdgcn_perm(z, C, sel_r);
+            Lw = l2;
+            C = c2;
+        }
+        if (r + PF < kBlurRows + 6) {
+            const int vo = INNER ? (int)(vbase + (uint32_t)((r + PF) * spitch)) : reflect101(min(y0 + r + PF - 3, h + 2), h) * spitch + vcol;
+            qC[r % PF] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0, 0);
         }
         const uint32_t a0 = __builtin_amdgcn_alignbyte(C, Lw, 1), b0 = __builtin_amdgcn_alignbyte(R, C, 1);
         const uint32_t a1 = __builtin_amdgcn_alignbyte(C, Lw, 2), b1 = __builtin_amdgcn_alignbyte(R, C, 2);
@@ -392,7 +422,7 @@ __device__ __forceinline__ void blur_stream(const __amdgpu_buffer_rsrc_t rs, con
     }
 }
 
-__global__ __launch_bounds__(256) void k_blur7_all(BatchDev B, int frame_major) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur7_all(BatchDev B, int frame_major) {
     const int blk_all = frame_major ? blockIdx.y : blockIdx.x;
     const int frame = frame_major ? blockIdx.z * gridDim.x + blockIdx.x : blockIdx.y;
     if (frame >= B.nframes) return;
@@ -408,63 +438,6 @@ __global__ __launch_bounds__(256) void k_blur7_all(BatchDev B, int frame_major) 
 #endif
     uint8_t* D8 = L.blur + (uint64_t)frame * L.bplane;
     const int tid = threadIdx.x;
-    // streaming lanes store dwords x0 in [4, last_full]; edge blocks own [0,4) and [xs, w)
-    const int last_full = ((w - 7) >> 2) << 2;
-    const int xs = last_full + 4;
-    const int nmain = blur_main_blocks(w, h);
-    if (blk >= nmain) {
-        __shared__ uint16_t s_sum[kBlurEdgeRows + 6][10];
-        const int yb = (blk - nmain) * kBlurEdgeRows;
-        const int nright = w - xs;  // 3..6
-        if (tid < kBlurEdgeRows + 6) {
-            const int yy = reflect101(min(yb + tid - 3, h + 2), h);
-            // Everything the row contributes comes in with five dword loads issued together: columns 0..7 and
-            // xs-4..xs+7 (the lanes of a wave are rows a pitch apart, so every load instruction touches 64 cache
-            // lines: loading the 70 taps byte by byte cost more than the whole streaming part of a level's rim).
-            const uint32_t* row = reinterpret_cast<const uint32_t*>(S8 + (uint64_t)yy * spitch);
-            const uint32_t L0 = row[0], L1 = row[1];
-            const int xr = (xs >> 2) - 1;                           // dword index of column xs - 4
-            const uint32_t R0 = row[xr], R1 = row[xr + 1];
-            const uint32_t R2 = nright > 4 ? row[xr + 2] : 0u;      // columns xs+4.. exist only then
-            auto left = [&](int x) -> uint32_t {                     // columns 0..7
-                return ((x < 4 ? L0 : L1) >> (8 * (x & 3))) & 0xFFu;
-            };
-            auto right = [&](int x) -> uint32_t {                    // columns xs-4 .. w-1
-                const int o = x - (xs - 4);
-                return ((o < 4 ? R0 : o < 8 ? R1 : R2) >> (8 * (o & 3))) & 0xFFu;
-            };
-            for (int e = 0; e < 10; ++e) {
-                uint32_t rs = 0;
-                if (e < 4) {
-#pragma unroll
-                    for (int t = 0; t < 7; ++t) rs += gauss_tap(t) * left(reflect101(e + t - 3, w));
-                } else if (e < 4 + nright) {
-#pragma unroll
-                    for (int t = 0; t < 7; ++t) rs += gauss_tap(t) * right(reflect101(xs + (e - 4) + t - 3, w));
-                }
-                s_sum[tid][e] = (uint16_t)rs;
-            }
-        }
-        __syncthreads();
-        if (tid < kBlurEdgeRows && yb + tid < h) {
-            uint8_t* drow = D8 + (uint64_t)(yb + tid) * dpitch;
-            // the columns leave as dwords (rows and xs are dword-aligned): a byte store is a partial write of its own
-            // to the memory system
-            uint32_t packed[3] = {0, 0, 0};
-            for (int e = 0; e < 4 + nright; ++e) {
-                uint32_t acc = 0;
-#pragma unroll
-                for (int j = 0; j < 7; ++j) acc += gauss_tap(j) * s_sum[tid + j][e];
-                packed[e >> 2] |= min(255u, (acc + 32768u) >> 16) << (8 * (e & 3));
-            }
-            // (the dwords that reach beyond the image end in the row's padding: the pitch is a multiple of 64 and
-            // nothing reads the padding)
-            *reinterpret_cast<uint32_t*>(drow) = packed[0];
-            *reinterpret_cast<uint32_t*>(drow + xs) = packed[1];
-            if (nright > 4) *reinterpret_cast<uint32_t*>(drow + xs + 4) = packed[2];
-        }
-        return;
-    }
     const int nd = (w + 3) >> 2, nty = (h + kBlurRows - 1) / kBlurRows;
     // A wave covers 62 consecutive pairs with lanes 1..62; lanes 0 and 63 load the pairs before and
     // after them and only serve as the left / right neighbour of lanes 1 and 62, so that every lane
@@ -482,18 +455,30 @@ __global__ __launch_bounds__(256) void k_blur7_all(BatchDev B, int frame_major) 
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(S8), 0, h * spitch, 0x00020000);
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(D8, 0, h * dpitch, 0x00020000);
     const int kOut = 0x7FFFFFF0;
-    // A lane whose neighbour lane holds another row tile (the first and last column of a tile) never
-    // stores: those columns belong to the edge blocks.
-    const bool store_ok = live && x0 >= 4 && x0 <= last_full && lane >= 1 && lane <= 62;
+    const bool store_ok = live && lane >= 1 && lane <= 62;
     const int vcol = live ? x0 : kOut;
+    // Rim columns.  In the first dword column the left neighbour is columns 3, 2, 1 of the lane's own dword; in the last
+    // one (which may reach into the row's padding: the pitch is a multiple of 64 and nothing reads the padding) the
+    // bytes beyond the width and the right neighbour are reflected columns of the lane's own and its left dword; in
+    // the one before, the right neighbour's bytes beyond the width come from the lane's own dword.
+    const bool last_col = live && dcol == nd - 1;
+    const bool rim = live && (dcol == 0 || dcol >= nd - 2);
+    const uint32_t sel_l = blur_rim_selector(x0 - 4, x0, x0 - 4, w);
+    const uint32_t sel_c = blur_rim_selector(x0, x0, x0 - 4, w);
+    const uint32_t sel_r = blur_rim_selector(x0 + 4, last_col ? x0 - 4 : x0 + 4, x0, w);
     // Row tiles whose 38 source rows all lie inside the image need no reflection and no row checks: their row
     // offsets are the lane's first offset plus a scalar multiple of the pitch (about a fifth fewer vector
     // instructions).  The choice is made per wave; idle lanes go along with either path.
     const bool inner = !live || (y0 >= 3 && y0 + kBlurRows + 2 < h);
-    if (__builtin_amdgcn_ballot_w64(!inner) == 0)
-        blur_stream<true>(rs, rd, y0, h, spitch, dpitch, vcol, x0, store_ok);
+    const bool all_inner = __builtin_amdgcn_ballot_w64(!inner) == 0, any_rim = __builtin_amdgcn_ballot_w64(rim) != 0;
+    if (all_inner && !any_rim)
+        blur_stream<true, false>(rs, rd, y0, h, spitch, dpitch, vcol, x0, store_ok, 0, 0, 0, false);
+    else if (all_inner)
+        blur_stream<true, true>(rs, rd, y0, h, spitch, dpitch, vcol, x0, store_ok, sel_l, sel_c, sel_r, last_col);
+    else if (!any_rim)
+        blur_stream<false, false>(rs, rd, y0, h, spitch, dpitch, vcol, x0, store_ok, 0, 0, 0, false);
     else
-        blur_stream<false>(rs, rd, y0, h, spitch, dpitch, vcol, x0, store_ok);
+        blur_stream<false, true>(rs, rd, y0, h, spitch, dpitch, vcol, x0, store_ok, sel_l, sel_c, sel_r, last_col);
 }
 
 }  // namespace orbx

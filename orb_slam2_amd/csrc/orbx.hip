@@ -484,7 +484,7 @@ void fill_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_p
         D.size = (float)(int)(31 * c->tab.scale[l]);  // reference :930
         dense_off += g.max_cand;
         kp_off += g.max_kp;
-        B.blur_first[l + 1] = B.blur_first[l] + blur_main_blocks(g.w, g.h) + blur_edge_blocks(g.h);
+        B.blur_first[l + 1] = B.blur_first[l] + blur_main_blocks(g.w, g.h);
     }
 }
 
