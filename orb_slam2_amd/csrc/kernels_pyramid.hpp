@@ -463,14 +463,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // the one before, the right neighbour's bytes beyond the width come from the lane's own dword.
     const bool last_col = live && dcol == nd - 1;
     const bool rim = live && (dcol == 0 || dcol >= nd - 2);
-    const uint32_t sel_l = blur_rim_selector(x0 - 4, x0, x0 - 4, w);
-    const uint32_t sel_c = blur_rim_selector(x0, x0, x0 - 4, w);
-    const uint32_t sel_r = blur_rim_selector(x0 + 4, last_col ? x0 - 4 : x0 + 4, x0, w);
+    uint32_t sel_l = 0, sel_c = 0, sel_r = 0;
     // Row tiles whose 38 source rows all lie inside the image need no reflection and no row checks: their row
     // offsets are the lane's first offset plus a scalar multiple of the pitch (about a fifth fewer vector
     // instructions).  The choice is made per wave; idle lanes go along with either path.
     const bool inner = !live || (y0 >= 3 && y0 + kBlurRows + 2 < h);
     const bool all_inner = __builtin_amdgcn_ballot_w64(!inner) == 0, any_rim = __builtin_amdgcn_ballot_w64(rim) != 0;
+    if (any_rim) {  // three waves in five hold no rim lane and skip the selectors
+        sel_l = blur_rim_selector(x0 - 4, x0, x0 - 4, w);
+        sel_c = blur_rim_selector(x0, x0, x0 - 4, w);
+        sel_r = blur_rim_selector(x0 + 4, last_col ? x0 - 4 : x0 + 4, x0, w);
+    }
     if (all_inner && !any_rim)
         blur_stream<true, false>(rs, rd, y0, h, spitch, dpitch, vcol, x0, store_ok, 0, 0, 0, false);
     else if (all_inner)
