@@ -61,7 +61,11 @@ __device__ __forceinline__ void sincos_pinned(float angf, float* c_out, float* s
 }
 
 constexpr int kPatchRows = 37, kPatchDw = 10, kPatchPitch = 40;  // blurred neighbourhood of a keypoint in LDS
-constexpr int kPatchLoads = (kPatchRows * kPatchDw + 63) / 64;      // dwords per lane
+// Dwords per lane.  Only the dwords the rotated pattern can reach are loaded: its farthest point is (13, 13), radius
+// sqrt(338), and a sample that rounds to row n lies at least |n| - 0.5 from the centre row, so its column is at most
+// rint(sqrt(338 - (|n| - 0.5)^2)): 13 columns in the outermost rows, all 37 in the middle ones, 310 dwords in all
+// (build_describe_lane_table lists them, with 1 % added to the squared radius) instead of 370.
+constexpr int kPatchLoads = 5;
 constexpr int kDescPerWave = 4;              // keypoints a wave handles in turn
 constexpr int kDescKp = 4 * kDescPerWave;    // keypoints per workgroup
 
@@ -85,7 +89,7 @@ typedef u32_unaligned desc_u32_unaligned;
 //   v2  v, column offset 16 * half - 15, 0, 0                                (v = row - 15)
 //   v3, v4      x of the lane's eight pattern points (float32 bits)          (tests 4l .. 4l + 3)
 //   v5, v6      y of the same points
-//   v7, v8      six patch-staging entries: LDS offset | (row - 18) << 16 | (4 * dword - 18) << 24
+//   v7, v8      kPatchLoads patch-staging entries: LDS offset | (row - 18) << 16 | (4 * dword - 18) << 24
 constexpr int kDescTabVec = 9;
 inline void build_describe_lane_table(const int8_t* pattern /* 512 (x, y) pairs */, uint32_t* tab /* [9][64][4] */) {
     // Row half-widths of the radius-15 disc (reference src/ORBextractor.cc:473-493).
@@ -111,10 +115,16 @@ inline void build_describe_lane_table(const int8_t* pattern /* 512 (x, y) pairs 
             std::memcpy(&v[3 + e / 4][e % 4], &fx, 4);
             std::memcpy(&v[5 + e / 4][e % 4], &fy, 4);
         }
-        for (int t = 0; t < 6; ++t) {
-            int it = lane + 64 * t;
-            if (it > 37 * 10 - 1) it = 37 * 10 - 1;
-            const int r = it / 10, k = it - r * 10;
+        for (int t = 0; t < kPatchLoads; ++t) {
+            // entry lane + 64 t of the row-major list of the dwords inside the pattern's reach (the spare entries at the
+            // end repeat the last one)
+            int want = lane + 64 * t, seen = 0, r = 0, k = 0;
+            for (int rr = 0; rr < kPatchRows; ++rr) {
+                const double m = std::max(std::abs(rr - 18) - 0.5, 0.0);
+                const int c = std::min(18, (int)std::floor(std::sqrt(338.0 * 1.01 - m * m) + 0.5));
+                for (int kk = (18 - c) / 4; kk <= (18 + c) / 4; ++kk, ++seen)
+                    if (seen <= want) r = rr, k = kk;
+            }
             v[7 + t / 4][t % 4] = (uint32_t)(r * 40 + 4 * k) | ((uint32_t)((r - 18) & 0xFF) << 16) | ((uint32_t)((4 * k - 18) & 0xFF) << 24);
         }
         for (int q = 0; q < kDescTabVec; ++q)
@@ -158,6 +168,10 @@ __global__ __launch_bounds__(256) void k_orient_describe(BatchDev B, const uint3
     __shared__ float s_a[kDescKp], s_b[kDescKp];
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[4][kPatchRows * kPatchPitch];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // This kernel allocates exactly 64 registers per lane, like FAST and the blur, whose waves it shares the SIMDs
+    // with: a retiring wave then leaves a slice of the register file that fits a wave of either of them.  (With the
+    // 56 registers it needs, the extraction step got 6 % slower although this kernel alone got faster.)
+    asm volatile("" ::: "v63");
     const int per_frame = B.nlevels * kp_blocks;
     const int xl = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int frame = (j / per_frame) * 8 + xl;
@@ -270,7 +284,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(BatchDev B, const uint3
 
     // ---- C. rotated BRIEF tests on the blurred level ----
     // The 37x37 neighbourhood the rotated pattern can reach (|coordinate| <= 18) is copied to LDS
-    // with coalesced row loads (37 rows x 10 dwords, 6 per lane, the next keypoint's rows in flight
+    // with coalesced row loads (the 310 dwords of its 37 rows that the pattern can reach, 5 per lane, the next keypoint's rows in flight
     // while this one is evaluated); the 512 scattered samples are then LDS byte reads, so the
     // vector cache sees each patch line once instead of once per gather instruction.
     const uint8_t* blur = L.blur + (uint64_t)frame * L.bplane;
