@@ -629,9 +629,13 @@ __global__ __launch_bounds__(256) void k_fast_tiles(BatchDev B, const TileDesc* 
                 if (dst[k] >= 0) *reinterpret_cast<u32x4*>(&s_tile[dst[k]]) = reg[k];
         }
     }
-    for (int i = tid; i < plane_bytes >> 2; i += 256) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
-    // the padding items at the end of each verdict row are never written by step 1 and must read as "no hit"
-    for (int i = tid; i < verdict_bytes >> 2; i += 256) reinterpret_cast<uint32_t*>(s_verdict)[i] = 0;
+    // score plane and verdict plane start at zero (16 bytes per store: every size of the carve-up is a multiple of 16).
+    // The padding items at the end of each verdict row are never written by step 1 and must read as "no hit".
+    {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        for (int i = tid; i < plane_bytes >> 4; i += 256) reinterpret_cast<u32x4*>(s_score)[i] = u32x4{0, 0, 0, 0};
+        for (int i = tid; i < verdict_bytes >> 4; i += 256) reinterpret_cast<u32x4*>(s_verdict)[i] = u32x4{0, 0, 0, 0};
+    }
     if (tid < kFastTileCells) {
         sh.kept[tid] = 0;
         sh.th[tid] = 0;
