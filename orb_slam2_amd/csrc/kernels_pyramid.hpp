@@ -75,7 +75,6 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     __syncthreads();
     const int lx = (tid & 63) * 4;
     if (lx >= ncol) return;
-    const int nvalid = min(4, ncol - lx);
     ResizeTap tx[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) tx[k] = s_xt[min(lx + k, ncol - 1)];
@@ -128,12 +127,8 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
                 out |= (uint32_t)v << (8 * k);
             }
         }
-        uint8_t* d = D + (uint64_t)(dy_first + ly) * dpitch;
-        if (nvalid == 4) {
-            *reinterpret_cast<uint32_t*>(d) = out;
-        } else {
-            for (int k = 0; k < nvalid; ++k) d[k] = (uint8_t)(out >> (8 * k));
-        }
+        // the last dword of a row is stored whole, as in k_resize_rows: the spill lands in the row's padding
+        *reinterpret_cast<uint32_t*>(D + (uint64_t)(dy_first + ly) * dpitch) = out;
     }
 }
 
