@@ -207,7 +207,12 @@ __global__ __launch_bounds__(256) void k_resize_rows(const uint8_t* __restrict__
             uint32_t X[4];
 #pragma unroll
             for (int px = 0; px < 4; ++px) X[px] = udot2(__builtin_amdgcn_perm(v.y, v.x, sel[px]), coef[px], 0u) & 0x00FFFF00u;
-            while (y < y_end && (int)(t_cur.x >> 16) == sr) {
+            // The destination rows whose second source row this is: one at most, or two where the taps are clamped
+            // to the image's last row (the launcher checks it).  Two conditional blocks and not a loop: vector-memory
+            // loads and stores are counted by one in-order counter, and behind a loop with an unknown number of
+            // stores the compiler must wait for every outstanding load before it may read the oldest one, which
+            // empties the load pipeline once per source row.
+            auto emit = [&]() {
                 if ((int)(t_cur.x & 0xFFFFu) == sr) {  // both taps on one row (the clamped last rows)
 #pragma unroll
                     for (int px = 0; px < 4; ++px) Xp[px] = X[px];
@@ -227,7 +232,9 @@ __global__ __launch_bounds__(256) void k_resize_rows(const uint8_t* __restrict__
                 ++y;
                 t_cur = t_nxt;
                 t_nxt = resize_row_tap(yt, min(y + 1, dh - 1));
-            }
+            };
+            if (y < y_end && (int)(t_cur.x >> 16) == sr) emit();
+            if (y < y_end && (int)(t_cur.x >> 16) == sr) emit();
 #pragma unroll
             for (int px = 0; px < 4; ++px) Xp[px] = X[px];
         }

@@ -333,6 +333,8 @@ int set_geometry(orbx_ctx* c, int w, int h) {
             for (size_t d = 0; d < yt.size() && ok; ++d) {
                 ok = ok && (yt[d].ofs1 == yt[d].ofs || yt[d].ofs1 == yt[d].ofs + 1);
                 if (d) ok = ok && yt[d].ofs >= yt[d - 1].ofs && yt[d].ofs1 >= yt[d - 1].ofs1;
+                // a source row completes at most two destination rows (two only where the taps are clamped to the last row)
+                if (d >= 2) ok = ok && yt[d].ofs1 != yt[d - 2].ofs1;
             }
             c->rs_stream[l] = ok;
         }
