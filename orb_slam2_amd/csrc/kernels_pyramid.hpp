@@ -301,10 +301,10 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // right (pixels x0-4 .. x0-1 and x0+4 .. x0+7) from the neighbouring lanes, forms
 // the four row sums with v_alignbyte_b32 + v_dot4_u32_u8 (taps 18,34,49,55 | 49,34,18,0), keeps
 // the row sums of the last six rows packed in pairs and evaluates the column pass with
-// v_dot2_u32_u16, storing one dword per row.  Rows are reflected by index.  Dwords holding a
-// column whose 7-tap window leaves the image (columns [0,4) and the last 3..6) are not stored by
-// streaming lanes (their store offset is pushed out of the buffer's range); "edge" blocks compute
-// those columns through a small LDS tile of row sums.
+// v_dot2_u32_u16, storing one dword per row.  Rows are reflected by index.  In the first and the
+// last two dword columns of a row, whose 7-tap windows leave the image, the neighbour dwords (and the
+// last dword's bytes beyond the width) are rebuilt from the reflected columns by byte permutations
+// (blur_rim_selector); only the waves that hold such a lane run that variant of the loop.
 // grid = (B.blur_first[nlevels], frames), block = 256; or, frame_major, (frames of a group of 8,
 // B.blur_first[nlevels], groups): workgroups go to the XCDs round-robin in x-fastest order, so the
 // blocks of a frame, which share halo rows and neighbour columns, then meet in one L2.
@@ -332,12 +332,7 @@ __device__ __forceinline__ uint32_t blur_pack(uint32_t v0, uint32_t v1, uint32_t
     return __builtin_amdgcn_perm(s23, s01, 0x05040100u);
 }
 
-__device__ __forceinline__ uint32_t gauss_tap(int j) {
-    const int k = j < 4 ? j : 6 - j;
-    return k == 0 ? 18u : k == 1 ? 34u : k == 2 ? 49u : 55u;
-}
-
-// Block counts of one level: streaming blocks, then edge blocks.
+// Blocks of one level.
 __host__ __device__ inline int blur_main_blocks(int w, int h) {
     const int nd = (w + 3) >> 2, nty = (h + kBlurRows - 1) / kBlurRows;
     return (nd * nty + kBlurItems - 1) / kBlurItems;
