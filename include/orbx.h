@@ -27,8 +27,9 @@ enum {
     ORBX_E_HIP = -2,       /* a HIP runtime call failed (see orbx_last_hip_error) */
     ORBX_E_NO_DEVICE = -3, /* no usable GPU */
     ORBX_E_CAPACITY = -4,  /* image/batch larger than the context was created for, or kp_cap too small */
-    ORBX_E_GEOMETRY = -5,  /* pyramid level too small for the 30-px cell grid, or too wide */
-    ORBX_E_STATE = -6      /* no extraction has run yet (pyramid read-back) */
+    ORBX_E_GEOMETRY = -5,  /* pyramid level too small for the 30-px cell grid (under 62 px), wider or higher than
+                              4127 px, or with a feature quota above 8189 */
+    ORBX_E_STATE = -6      /* no extraction has run yet (pyramid read-back), or the intermediate asked for is gone */
 };
 
 /* Same field order and size (28 bytes) as cv::KeyPoint. */
