@@ -89,6 +89,13 @@ int orbx_host_level_geometry(int nfeatures, float scale_factor, int nlevels,
  * zeroed); 0 applies the vertical rule (index left unclamped, may be -1 or sn-1). */
 int orbx_host_resize_taps(int sn, int dn, int clamp_index, int32_t* ofs, int16_t* c0, int16_t* c1);
 
+/* The byte selector (v_perm_b32 convention: values 4..7 pick from the dword that holds columns hi_col..hi_col+3,
+ * values 0..3 from the one that holds lo_col..lo_col+3) with which the blur kernel builds the dword of columns
+ * target_col..target_col+3 of a row of `width` pixels at the image's left and right rim, where cv::GaussianBlur's
+ * BORDER_REFLECT_101 (call site src/ORBextractor.cc:1188) mirrors the columns.  Host-side copy of the device
+ * function, exported so that the rim arithmetic can be tested without a GPU. */
+uint32_t orbx_host_blur_rim_selector(int target_col, int hi_col, int lo_col, int width);
+
 /* Upper bound on keypoints returned per image for these parameters and image size. */
 int orbx_host_max_keypoints(int nfeatures, float scale_factor, int nlevels, int width, int height);
 

@@ -46,7 +46,7 @@ class LevelGeom(C.Structure):
 
 
 EXPORTS = [
-    "orbx_host_tables", "orbx_host_level_geometry", "orbx_host_resize_taps", "orbx_host_max_keypoints",
+    "orbx_host_tables", "orbx_host_level_geometry", "orbx_host_resize_taps", "orbx_host_max_keypoints", "orbx_host_blur_rim_selector",
     "orbx_create", "orbx_destroy", "orbx_extract", "orbx_extract_batch", "orbx_extract_batch_device",
     "orbx_synchronize", "orbx_pyramid_level", "orbx_debug_read", "orbx_set_profiling", "orbx_get_stage_ms",
     "orbx_stage_name", "orbx_strerror", "orbx_last_hip_error", "orbx_version",
@@ -79,6 +79,8 @@ def load_library():
     L.orbx_host_level_geometry.argtypes = [i32, f32, i32, i32, i32, i32, C.POINTER(LevelGeom)]
     L.orbx_host_resize_taps.argtypes = [i32, i32, i32, vp, vp, vp]
     L.orbx_host_max_keypoints.argtypes = [i32, f32, i32, i32, i32]
+    L.orbx_host_blur_rim_selector.argtypes = [i32, i32, i32, i32]
+    L.orbx_host_blur_rim_selector.restype = C.c_uint32
     L.orbx_create.argtypes = [C.POINTER(_Params), C.POINTER(vp)]
     L.orbx_destroy.argtypes = [vp]
     L.orbx_destroy.restype = None

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void k_resize_chain(ResizeChain C) {
     C.dst[k][(uint64_t)blockIdx.z * C.dplane[k] + (uint64_t)y * C.dpitch[k] + x] = (uint8_t)v;
 }
 
-__device__ __forceinline__ int reflect101(int p, int len) {
+__host__ __device__ __forceinline__ int reflect101(int p, int len) {
     p = p < 0 ? -p : p;
     return p >= len ? 2 * len - 2 - p : p;
 }
@@ -342,7 +342,7 @@ __host__ __device__ inline int blur_main_blocks(int w, int h) {
 // Selector of a v_perm_b32 that builds the dword of columns tb .. tb+3 of a row of width w, reflected at the image's
 // sides (BORDER_REFLECT_101), from two dwords: `hi` holds columns hb .. hb+3 (selector values 4..7), `lo` columns
 // lb .. lb+3 (values 0..3).  Columns no tap can reach (more than 3 outside the image) get byte 0 of `lo`.
-__device__ __forceinline__ uint32_t blur_rim_selector(int tb, int hb, int lb, int w) {
+__host__ __device__ __forceinline__ uint32_t blur_rim_selector(int tb, int hb, int lb, int w) {
     uint32_t sel = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

@@ -2095,6 +2095,10 @@ extern "C" int orbx_debug_read(orbx_ctx* c, int what, int img_idx, int level, vo
     return ORBX_E_INVALID;
 }
 
+extern "C" uint32_t orbx_host_blur_rim_selector(int target_col, int hi_col, int lo_col, int width) {
+    return blur_rim_selector(target_col, hi_col, lo_col, width);
+}
+
 extern "C" int orbx_set_debug_flag(orbx_ctx* c, int flag, int value) {
     if (!c) return ORBX_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->prm.device_id));

@@ -104,3 +104,43 @@ def test_cpp_class_getters(oracle):
         vals = [np.float32(v) for v in out[1 + l].split()]
         assert vals == [np.float32(p.scale[l]), np.float32(p.inv_scale[l]), np.float32(p.sigma2[l]),
                         np.float32(p.inv_sigma2[l])]
+
+
+@pytest.mark.parametrize("w", list(range(62, 140)) + [317, 640, 752, 1241, 1242, 1243, 1244, 3840, 4127])
+def test_blur_rim_selectors_reproduce_reflect_101(w):
+    """The blur kernel rebuilds the neighbour dwords of a row's first and last two dword columns (and the last dword's
+    bytes beyond the width) with byte permutations.  Here the selectors the library computes are applied, in
+    numpy, to a row with arbitrary bytes in its padding, and every pixel's 7-tap row sum is compared with the sum
+    over cv::GaussianBlur's BORDER_REFLECT_101 columns (reference call site src/ORBextractor.cc:1188)."""
+    L = oa.load_library()
+    taps = [18, 34, 49, 55, 49, 34, 18]
+    rng = np.random.default_rng(w)
+    pitch = (w + 63) // 64 * 64
+    row = rng.integers(0, 256, pitch).astype(np.int64)       # the padding holds arbitrary bytes
+    nd = (w + 3) // 4
+
+    def reflect(p):
+        p = -p if p < 0 else p
+        return 2 * w - 2 - p if p >= w else p
+
+    def dword(d):                                             # a neighbour outside the row belongs to another tile
+        return [-10**6] * 4 if d < 0 or d >= nd else list(row[4 * d:4 * d + 4])
+
+    def perm(hi, lo, sel):
+        both = list(lo) + list(hi)
+        return [both[(sel >> (8 * k)) & 7] for k in range(4)]
+
+    for dcol in [0, 1, nd - 3, nd - 2, nd - 1]:
+        x0 = 4 * dcol
+        c, lw, r = dword(dcol), dword(dcol - 1), dword(dcol + 1)
+        last = dcol == nd - 1
+        sel_l = L.orbx_host_blur_rim_selector(x0 - 4, x0, x0 - 4, w)
+        sel_c = L.orbx_host_blur_rim_selector(x0, x0, x0 - 4, w)
+        sel_r = L.orbx_host_blur_rim_selector(x0 + 4, x0 - 4 if last else x0 + 4, x0, w)
+        z = lw if last else r
+        window = perm(c, lw, sel_l) + perm(c, lw, sel_c) + perm(z, c, sel_r)   # columns x0-4 .. x0+7
+        for k in range(4):
+            x = x0 + k
+            if x < w:
+                got = sum(t * window[4 + k - 3 + i] for i, t in enumerate(taps))
+                assert got == sum(t * row[reflect(x - 3 + i)] for i, t in enumerate(taps)), (w, dcol, k)
