@@ -144,3 +144,17 @@ def test_blur_rim_selectors_reproduce_reflect_101(w):
             if x < w:
                 got = sum(t * window[4 + k - 3 + i] for i, t in enumerate(taps))
                 assert got == sum(t * row[reflect(x - 3 + i)] for i, t in enumerate(taps)), (w, dcol, k)
+
+
+@pytest.mark.parametrize("scale", [1.1, 1.2, 1.25, 1.3, 1.5, 2.0])
+def test_a_source_row_completes_at_most_two_destination_rows(scale):
+    """The streaming resize kernel emits the destination rows whose second tap is the source row just filtered
+    with two conditional blocks, not a loop: for every down-scaling level of a pyramid no three destination rows
+    may share their second source row (two do where the taps are clamped to the image's last row)."""
+    for sn in list(range(62, 400, 7)) + [480, 752, 1241, 2160, 3840]:
+        dn = int(np.rint(np.float32(sn) * (np.float32(1.0) / np.float32(scale))))
+        if dn < 8:
+            continue
+        ofs, c0, c1 = oa.host_resize_taps(sn, dn, False)
+        ofs1 = np.minimum(ofs + 1, sn - 1)
+        assert (ofs1[2:] != ofs1[:-2]).all(), (sn, dn)
