@@ -426,16 +426,60 @@ def host_to_host(oa, run):
     return e
 
 
+def self_launch(n):
+    """`bench.py --gpus N` started without a launcher (no WORLD_SIZE in the environment): starts the N ranks as fresh
+    child processes -- one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set per child, the same command line --
+    before anything in this process has touched a GPU, waits for them and returns the worst exit code.  Rank 0
+    prints the JSON line.  Fewer than N devices is an error, not a smaller run (ORBX_BENCH_BACKEND=gloo, the
+    rehearsal on a box with fewer GPUs than ranks, lets ranks share devices)."""
+    import socket
+    import torch   # device_count() does not initialise the GPU
+    have = torch.cuda.device_count()
+    if os.environ.get("ORBX_BENCH_BACKEND", "nccl") == "nccl" and have < n:
+        sys.stderr.write("bench.py: --gpus %d but this node has %d device(s)\n" % (n, have))
+        return 2
+    if have < 1:
+        sys.stderr.write("bench.py: no GPU\n")
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst, live = 0, list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0 and not worst:
+                worst = rc if rc > 0 else 1
+                for q in live:   # a rank that died leaves the others in a barrier: end them (exact PIDs, started here)
+                    q.terminate()
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--pairs", type=int, default=PAIRS)
-    ap.add_argument("--config", choices=("c3", "c4"), default="c3")
+    ap.add_argument("--config", choices=("c3", "c4", "c5"), default="c3")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the other configurations and the consumers")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started without a launcher: this process starts the ranks itself and never touches a GPU
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -445,8 +489,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
+        # never a line that reports fewer GPUs than were asked for
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if os.environ.get("ORBX_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < (local_rank + 1 if world > 1 else 1):
+        raise SystemExit("rank %d needs device %d, the node has %d" % (rank, local_rank, torch.cuda.device_count()))
     # ORBX_BENCH_BACKEND=gloo rehearses the multi-process flow on a box with fewer GPUs than ranks
     # (ranks then share devices); the measured configuration is one rank per GPU over RCCL ("nccl").
     backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")
@@ -474,6 +521,16 @@ def main():
         scaling = "weak"
         workload = ("KITTI stereo 1241x376 left+right, 2000 features/image, 8 levels, scale 1.2, FAST 20/7, %d pairs (%d frames) "
                     "per step per GPU, frames resident in HBM" % (args.pairs, n))
+    elif args.config == "c5":
+        # the 4K configuration as the measured step (profiles of its kernels); `extras` reports the same step
+        cfg, n = C5, min(128, 2 * args.pairs)
+        run = DeviceRun(torch, oa, cfg, n, local_rank, first_idx=2000 + rank, n_base=2)
+        job_frames = world * n
+        rank_frames = n
+        step = run.step
+        scaling = "weak"
+        workload = ("3840x2160, 8000 features/image, 12 levels, scale 1.2, FAST 20/7, %d frames per step per GPU, frames "
+                    "resident in HBM" % n)
     else:
         cfg = C4
         first, last = shard.frame_shard(C4_STREAM, rank, world)   # strong scaling: the stream is cut over the ranks
@@ -595,8 +652,9 @@ def main():
             "valu_issue": valu_view(dom, n, serial_sum[dom]),
         }
         out = {
-            "metric": "ORB frames/sec (1241x376, 2000 kp, 8 lvl)" if args.config == "c3" else
-                      "ORB frames/sec (752x480 EuRoC stream of 8192 frames, 1200 kp, 8 lvl)",
+            "metric": {"c3": "ORB frames/sec (1241x376, 2000 kp, 8 lvl)",
+                       "c4": "ORB frames/sec (752x480 EuRoC stream of 8192 frames, 1200 kp, 8 lvl)",
+                       "c5": "ORB frames/sec (3840x2160, 8000 kp, 12 lvl)"}[args.config],
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",

@@ -29,7 +29,14 @@ enum {
     ORBX_E_CAPACITY = -4,  /* image/batch larger than the context was created for, or kp_cap too small */
     ORBX_E_GEOMETRY = -5,  /* pyramid level too small for the 30-px cell grid (under 62 px), wider or higher than
                               4127 px, or with a feature quota above 8189 */
-    ORBX_E_STATE = -6      /* no extraction has run yet (pyramid read-back), or the intermediate asked for is gone */
+    ORBX_E_STATE = -6,     /* no extraction has run yet (pyramid read-back), or the intermediate asked for is gone */
+    ORBX_E_DEVICE_DATA = -7 /* a kernel read a count or a coordinate out of device memory that lay outside the array it
+                              indexes (memory the library does not own was overwritten, or a producer failed).  The
+                              kernel went on with the value cut to its bound -- nothing was accessed out of range, the
+                              GPU does not fault -- and the context reports this code from the next call that waits
+                              for the work (orbx_synchronize, a call with sync != 0, a host-memory entry point), once;
+                              the results of the batches enqueued since the last such call are invalid.  The reference
+                              has no counterpart (its lists are std::vectors on the host). */
 };
 
 /* Same field order and size (28 bytes) as cv::KeyPoint. */
@@ -557,7 +564,7 @@ int orbx_stereo_match_batch_device(orbx_ctx* ctx, int n_pairs, const orbx_kp* d_
                                    float* d_u_right, float* d_depth, int sync);
 
 /* orbx_stereo_match_batch_device for callers that cannot allocate device memory: code under HIP
- * graph capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the
+ * graph capture elsewhere in the process, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the
  * reference.  Same arguments, same results; the kernels' scratch (row table, bucketed right
  * keypoints, window distances) lives in a fixed array inside the library instead of buffers the
  * context grows on demand, and the call makes no hipMalloc, hipFree or other allocating call.
@@ -565,9 +572,12 @@ int orbx_stereo_match_batch_device(orbx_ctx* ctx, int n_pairs, const orbx_kp* d_
  * up to 256, must fit ORBX_NOALLOC_SCRATCH_BYTES (8 MiB: 248 KITTI-shape pairs at kp_cap 2008);
  * beyond that, or kp_cap > 16384, the call returns ORBX_E_CAPACITY and does nothing.  Each GPU
  * the library runs on holds one copy of the array until the process ends, and every call on
- * that GPU -- from any context -- uses it: two such calls that overlap in time on one GPU race,
- * so synchronise one before the next is enqueued (calls on one context are stream-ordered and
- * safe).  Nothing in the array has to start at zero; it keeps the last call's contents. */
+ * that GPU -- from any context -- uses it, one after the other: a call waits on its stream for
+ * the kernels of the previous call on that GPU (an event per GPU, recorded behind each call's
+ * kernels), so two contexts on one GPU take turns on the array and never overlap on it.  Nothing
+ * in the array has to start at zero; it keeps the last call's contents.  The launches go to the
+ * context's own stream like those of every other entry point: a caller's stream capture does not
+ * see them. */
 #define ORBX_NOALLOC_SCRATCH_BYTES ((size_t)8 << 20)
 int orbx_stereo_match_batch_device_noalloc(orbx_ctx* ctx, int n_pairs, const orbx_kp* d_kps, int kp_cap,
                                            const uint8_t* d_desc, const int32_t* d_n, float mb, float mbf,
@@ -607,7 +617,11 @@ enum {
     ORBX_FLAG_TRACE = 4,              /* timing prints of the host batch path on stderr              */
     ORBX_FLAG_NO_GRAPH = 5,           /* orbx_extract issues its launches one by one, no HIP graph   */
     ORBX_FLAG_PIPE_CHUNK = 6,         /* frames per chunk of the pipelined host batch path (0: auto) */
-    ORBX_FLAG_INIT_LIST = 7           /* candidates per list of orbx_search_for_initialization_batch_device (0: default) */
+    ORBX_FLAG_INIT_LIST = 7,          /* candidates per list of orbx_search_for_initialization_batch_device (0: default) */
+    ORBX_FLAG_POISON = 8              /* test hook: from the next batch on, the device-side count of frame 0's first
+                                         FAST cell (1), of its first level's retained points (2), or its first
+                                         candidate point (3) is overwritten with an out-of-range value after its
+                                         producer has run; 0 switches it off.  The batch must end in ORBX_E_DEVICE_DATA. */
 };
 int orbx_set_debug_flag(orbx_ctx* ctx, int flag, int value);
 

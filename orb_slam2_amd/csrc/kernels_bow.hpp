@@ -933,7 +933,10 @@ __global__ __launch_bounds__(kProjThreads, 8) void k_search_local(LocalDev D) {
                 top2_row_merge(k1, k2, v1, v2);
                 if (k1 != 0xFFFFFFFFu) {
                     const int bestDist = (int)(k1 >> 23), bestLevel = v1 >> 20;
-                    const int bestDist2 = k2 == 0xFFFFFFFFu ? 256 : (int)(k2 >> 23), bestLevel2 = k2 == 0xFFFFFFFFu ? -1 : (v2 >> 20);
+                    // a candidate at distance 256 is never recorded by the reference (dist < bestDist2 fails against the initial
+                    // 256, :110-114): as a second best it leaves bestLevel2 at -1
+                    const bool no2 = k2 == 0xFFFFFFFFu || (k2 >> 23) >= 256u;
+                    const int bestDist2 = no2 ? 256 : (int)(k2 >> 23), bestLevel2 = no2 ? -1 : (v2 >> 20);
                     if (GUIDED) {
                         if (bestDist <= D.max_dist) outcome = best = v1 & 0xFFFFF;  // :1592, :394; the second best plays no part
                     } else if (bestDist <= kThHigh) {  // :118

@@ -81,7 +81,9 @@ __global__ __launch_bounds__(kBowMatchThreads, 8) void k_search_bow(BowMatchDev 
     extern __shared__ uint32_t s_taken[];
     __shared__ int s_nm, s_hist[kHistoLength], s_keep[3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, f = blockIdx.x;
-    const int nkf = D.fv_n_kf[f], nf = D.fv_n_f[f];
+    // the counts are cut to the arrays' capacities, as in the sibling kernels: a larger value would send the run
+    // search and the descriptor loads into the next pair's slice
+    const int nkf = max(0, min(D.fv_n_kf[f], D.cap_kf)), nf = max(0, min(D.fv_n_f[f], D.cap_f));
     const uint32_t* nodes_kf = D.fv_node_kf + (size_t)f * D.cap_kf;
     const uint32_t* idx_kf = D.fv_idx_kf + (size_t)f * D.cap_kf;
     const uint8_t* desc_kf = D.desc_kf + (size_t)f * D.cap_kf * 32;

@@ -179,10 +179,17 @@ __global__ __launch_bounds__(256) void k_orient_describe(BatchDev B, const uint3
     const int rem = j % per_frame;
     const int level = rem / kp_blocks, kblk = rem % kp_blocks;
     const int32_t* counts = lvl_count + (uint64_t)frame * B.nlevels;
-    const int n = counts[level];
+    // a level's count is trusted no further than the level's slot in the retained-point array (max_kp entries): a
+    // value outside it is cut to the slot and reported, so no point is read from beyond the slot
+    auto level_count = [&](int l) {
+        const int v = counts[l];
+        if ((unsigned)v > (unsigned)B.lv[l].max_kp && B.status) B.status[kStatusLevelCount] = 1u;
+        return max(0, min(v, B.lv[l].max_kp));
+    };
+    const int n = level_count(level);
     if (kblk == 0 && level == 0 && tid == 0) {
         int tot = 0;
-        for (int l = 0; l < B.nlevels; ++l) tot += counts[l];
+        for (int l = 0; l < B.nlevels; ++l) tot += level_count(l);
         out_n[frame] = min(tot, kp_cap);
     }
     const int first = kblk * kDescKp;
@@ -190,13 +197,21 @@ __global__ __launch_bounds__(256) void k_orient_describe(BatchDev B, const uint3
     const int nk = min(kDescKp, n - first);
     const LevelDev& L = B.lv[level];
     int base_out = 0;
-    for (int l = 0; l < level; ++l) base_out += counts[l];
+    for (int l = 0; l < level; ++l) base_out += level_count(l);
     base_out += first;
     unsigned long long t0 = 0;
 #ifdef ORBX_STAMPS_DESC
     t0 = __builtin_amdgcn_s_memtime();
 #endif
-    if (tid < nk) s_pk[tid] = lvl_kps[(uint64_t)frame * B.kp_total + L.kp_off + first + tid];
+    if (tid < nk) {
+        // the patches of phases A and C are read around the point: it must lie where the detector can put one
+        uint32_t pk = lvl_kps[(uint64_t)frame * B.kp_total + L.kp_off + first + tid];
+        if ((unsigned)(pt_x(pk) - 3) >= (unsigned)(L.rect_w - 6) || (unsigned)(pt_y(pk) - 3) >= (unsigned)(L.rect_h - 6)) {
+            if (B.status) B.status[kStatusPoint] = 1u;
+            pk = pack_pt(max(3, min(pt_x(pk), L.rect_w - 4)), max(3, min(pt_y(pk), L.rect_h - 4)), pt_score(pk));
+        }
+        s_pk[tid] = pk;
+    }
 
     // ---- lane constants (see build_describe_lane_table) ----
     uint4 tv[kDescTabVec];

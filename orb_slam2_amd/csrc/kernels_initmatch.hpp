@@ -42,7 +42,7 @@ inline size_t init_match_lds_bytes(int cap_1, int cap_2, int list_cap) {
 // grid = pairs of frames, block = 1024, dynamic LDS = init_match_lds_bytes(cap_1, cap_2, list_cap).
 __global__ __launch_bounds__(kInitThreads, 8) void k_search_init(InitDev D) {
     __shared__ int s_cnt[kInitGroups], s_hist[kHistoLength], s_keep[3], s_nm, s_wave[kInitThreads / 64];
-    extern __shared__ int32_t s_dyn[];
+    extern __shared__ __attribute__((aligned(16))) int32_t s_dyn[];  // the lists are read and written as 8-byte entries
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, sub = tid & 15, grp = tid >> 4;
     const int cap_1 = D.cap_1, cap_2 = D.W.kp_cap, lc = D.list_cap;
     uint2* s_list = reinterpret_cast<uint2*>(s_dyn);                                     // [64][lc] (key, feature | bin << 16)

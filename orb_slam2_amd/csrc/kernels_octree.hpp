@@ -122,7 +122,14 @@ __global__ __launch_bounds__(NT) void k_octree(BatchDev B, const uint32_t* __res
     // ---- prologue: gather the level's candidates into a dense array, in cell order ----------
     uint32_t* s_prefix = reinterpret_cast<uint32_t*>(s_raw);
     const uint64_t slot0 = (uint64_t)frame * B.total_cells + L.cell_base;
-    for (int c = tid; c < L.n_cells; c += NT) s_prefix[c] = ccount[slot0 + c];
+    // A count is trusted no further than the slot it describes: a value above the slot's capacity (memory the
+    // library does not own was written, or a producer failed) is cut to it and reported, so that the sum stays within
+    // the dense arrays (n_cells * cell_cap entries per level) and every read of `cand` stays inside a slot.
+    for (int c = tid; c < L.n_cells; c += NT) {
+        const uint32_t v = ccount[slot0 + c];
+        if (v > (uint32_t)B.cell_cap && B.status) B.status[kStatusCellCount] = 1u;
+        s_prefix[c] = min(v, (uint32_t)B.cell_cap);
+    }
     if (tid == 0) s_prefix[L.n_cells] = 0;
     __syncthreads();
     const int C = (int)lds_excl_scan<NT>(s_prefix, L.n_cells + 1, s_wave4);
@@ -155,6 +162,13 @@ __global__ __launch_bounds__(NT) void k_octree(BatchDev B, const uint32_t* __res
         for (int k = 0; k < kPtBatch; ++k) {
             const int p = p0 + NT * k;
             if (p < C) {
+                // the detector leaves a 3-pixel rim of the detection rectangle free (cv::FAST's own border); a point
+                // outside [3, rect - 3) cannot come from it: it is moved inside (later stages read image patches around
+                // the retained points) and reported
+                if ((unsigned)(pt_x(v[k]) - 3) >= (unsigned)(L.rect_w - 6) || (unsigned)(pt_y(v[k]) - 3) >= (unsigned)(L.rect_h - 6)) {
+                    if (B.status) B.status[kStatusPoint] = 1u;
+                    v[k] = pack_pt(max(3, min(pt_x(v[k]), L.rect_w - 4)), max(3, min(pt_y(v[k]), L.rect_h - 4)), pt_score(v[k]));
+                }
                 pts[p] = v[k];
                 int r = (int)((float)pt_x(v[k]) / h_x);  // root of the point (:620)
                 r = min(r, L.n_ini - 1);

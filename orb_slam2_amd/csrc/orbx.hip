@@ -53,6 +53,12 @@ static __device__ __align__(256) uint8_t scratch[kScratchBytes];
 constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mutex;
 uint8_t* g_scratch_ptr[kMaxDevices];  // per device ordinal, null until looked up
+// The array has one user at a time per GPU: every call that uses it waits, on its own stream, for the event the
+// previous user recorded behind its kernels, and records the event again behind its own (under the mutex, so that
+// wait, launches and record of two contexts do not interleave).  Two contexts on one GPU -- the stereo pattern of two
+// extractor instances on two threads -- so take turns instead of racing.  Created with the address, never destroyed.
+hipEvent_t g_scratch_event[kMaxDevices];
+bool g_scratch_used[kMaxDevices];     // the event has been recorded at least once
 
 // Address of the current device's copy of `scratch` (device `dev` must be current).
 int scratch_address(int dev, uint8_t** out, int* hip_err) {
@@ -65,6 +71,13 @@ int scratch_address(int dev, uint8_t** out, int* hip_err) {
             *hip_err = (int)e;
             return ORBX_E_HIP;
         }
+        hipEvent_t ev;
+        const hipError_t e2 = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e2 != hipSuccess) {
+            *hip_err = (int)e2;
+            return ORBX_E_HIP;
+        }
+        g_scratch_event[dev] = ev;
         g_scratch_ptr[dev] = (uint8_t*)p;
     }
     *out = g_scratch_ptr[dev];
@@ -167,6 +180,11 @@ struct orbx_ctx {
     void* h_gout = nullptr;  // pinned: [cap keypoints][cap descriptors][count] (target of its download nodes)
 
     uint8_t* scratch = nullptr;  // this device's copy of the library's static scratch array
+    // kStatusWords words in pinned host memory that the kernels can write (see orbx_device.h): a kernel that meets a
+    // count or a coordinate outside its bounds sets one; sync_ctx reads them after the streams have drained
+    uint32_t* h_status = nullptr;
+    uint32_t* d_status = nullptr;  // the same words as the device addresses them
+    int dbg_poison = 0;            // test hook: 1 a cell count, 2 a level count, 3 a candidate point is overwritten on the device
 
     bool profiling = false;
     hipEvent_t ev[kEvCount];  // timing events, recorded when profiling is on
@@ -202,11 +220,22 @@ int wait_arena_free(orbx_ctx* c, int set, hipStream_t stream) {
     if (e >= 0 && c->desc_pending[e]) HIP_TRY(c, hipStreamWaitEvent(stream, c->ev_desc[e], 0));
     return ORBX_OK;
 }
+// Non-zero status words = some kernel since the last check read a value outside its bounds from device memory (it
+// went on with the value cut to the bound, so nothing was accessed out of range).  Reported once, then cleared.
+int check_status(orbx_ctx* c) {
+    if (!c->h_status) return ORBX_OK;
+    uint32_t any = 0;
+    for (int i = 0; i < kStatusWords; ++i) {
+        any |= reinterpret_cast<volatile uint32_t*>(c->h_status)[i];
+        c->h_status[i] = 0;
+    }
+    return any ? ORBX_E_DEVICE_DATA : ORBX_OK;
+}
 int sync_ctx(orbx_ctx* c) {
     int rc = join(c);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return ORBX_OK;
+    return check_status(c);
 }
 
 // Forgets the captured single-frame launch graph (see build_graph) and its pinned buffers.
@@ -445,6 +474,7 @@ void fill_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_p
     B.kp_total = c->kp_total;
     B.ini_th = c->prm.ini_th_fast;
     B.min_th = c->prm.min_th_fast;
+    B.status = c->d_status;
 #if defined(ORBX_STAMPS) || defined(ORBX_STAMPS_DESC)
     if (!c->d_stamps.p && ensure(c, &c->d_stamps, 1024 * 16 * 8) == ORBX_OK) (void)hipMemset(c->d_stamps.p, 0, 1024 * 16 * 8);
     B.stamps = (unsigned long long*)c->d_stamps.p;
@@ -495,11 +525,14 @@ int ensure_aux_streams(orbx_ctx* c) {
     if (c->aux_made) return ORBX_OK;
     // All streams at the default priority: with low-priority streams a wait on one of them from a
     // default-priority stream stalled for tens of seconds (measured with the chunked host path).
-    if (c->dbg_aux_low_priority) {  // diagnostic: the configuration in which the chunked host path stalled
+#ifdef ORBX_DIAG_LOW_PRIORITY  // diagnostic build only: the configuration in which the chunked host path stalled
+    if (c->dbg_aux_low_priority) {
         int least = 0, greatest = 0;
         HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIP_TRY(c, hipStreamCreateWithPriority(&c->st_aux, hipStreamNonBlocking, least));
-    } else {
+    } else
+#endif
+    {
         HIP_TRY(c, hipStreamCreateWithFlags(&c->st_aux, hipStreamNonBlocking));
     }
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
@@ -634,6 +667,13 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     if ((rc = mark(kEvFastB0, st))) return rc;
     launch_fast(overlap ? n_tiles0 : 0, overlap ? n_tiles - n_tiles0 : n_tiles);
     if ((rc = mark(kEvFastB1, st))) return rc;
+    // test hook (orbx_set_debug_flag, ORBX_FLAG_POISON): what the detector left for frame 0, cell 0 is overwritten,
+    // so that a test can see the consumers of device-side counts cut them to their bounds and report them
+    if (c->dbg_poison == 1) HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->d_ccount[kp_set].p, 0x7FFFFFFF, 1, st));
+    if (c->dbg_poison == 3) {
+        HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->d_ccount[kp_set].p, 1, 1, st));
+        HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->d_cand[kp_set].p, 0x00FFFFFF, 1, st));
+    }
     if (overlap) {
         // stage 3 (aux): blur of all levels.  It is held back until FAST has finished: started earlier
         // it only slows FAST down (both are bound by vector instruction issue), started here it runs
@@ -672,6 +712,7 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
                            (const uint32_t*)c->d_ccount[kp_set].p, (uint32_t*)c->d_dense_pts.p, (uint16_t*)c->d_dense_node.p,
                            (uint32_t*)c->d_lvl_kps[kp_set].p, (int32_t*)c->d_lvl_count[kp_set].p, (uint8_t*)nullptr, (size_t)0);
     if ((rc = mark(kEvOct1, so))) return rc;
+    if (c->dbg_poison == 2) HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->d_lvl_count[kp_set].p, 0x7FFFFFFF, 1, so));
     hipStream_t sd = st;  // stream of the descriptor stage
     if (overlap) {
         // stage 4 on its own stream, after the quadtree and the blur; the other streams are then free
@@ -1074,6 +1115,7 @@ int extract_graph(orbx_ctx* c, const uint8_t* img, int width, int height, int st
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->have_last = true;
     c->last_chunked = false;
+    { int rc_ = check_status(c); if (rc_) return rc_; }
     const uint8_t* o = (const uint8_t*)c->h_gout;
     int32_t k = 0;
     std::memcpy(&k, o + (size_t)cap * (sizeof(orbx_kp) + 32), 4);
@@ -1123,7 +1165,9 @@ extern "C" int orbx_create(const orbx_params* params, orbx_ctx** out) {
     c->dbg_stereo_border = std::getenv("ORBX_STEREO_BORDER_PATH") != nullptr;
     c->dbg_trace = std::getenv("ORBX_TRACE") != nullptr;
     c->dbg_no_graph = std::getenv("ORBX_NO_GRAPH") != nullptr;
+#ifdef ORBX_DIAG_LOW_PRIORITY
     c->dbg_aux_low_priority = std::getenv("ORBX_AUX_LOW_PRIORITY") != nullptr;
+#endif
     if (const char* e = std::getenv("ORBX_PIPE_CHUNK")) c->dbg_pipe_chunk = std::max(0, std::atoi(e));
     int rc = ORBX_OK;
     auto fail = [&](int code) {
@@ -1145,6 +1189,10 @@ extern "C" int orbx_create(const orbx_params* params, orbx_ctx** out) {
                             (int)init_match_lds_bytes(kInitMaxCap, kInitMaxCap, kInitListCap)) != hipSuccess)
         return fail(ORBX_E_HIP);
     if ((rc = scratch_address(params->device_id, &c->scratch, &c->last_hip))) return fail(rc);
+    if (hipHostMalloc((void**)&c->h_status, kStatusWords * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+        return fail(ORBX_E_HIP);
+    std::memset(c->h_status, 0, kStatusWords * sizeof(uint32_t));
+    if (hipHostGetDevicePointer((void**)&c->d_status, c->h_status, 0) != hipSuccess) return fail(ORBX_E_HIP);
     {
         std::vector<uint32_t> tab((size_t)kDescTabVec * 64 * 4);
         build_describe_lane_table(kPattern, tab.data());
@@ -1185,6 +1233,7 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
                       &c->d_st_sad, &c->d_st_u, &c->d_st_depth};
     for (DevBuf* b : bufs) release(b);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_status) (void)hipHostFree(c->h_status);
     for (int i = 0; i < kPipeSlots; ++i) {
         if (c->h_up[i]) (void)hipHostFree(c->h_up[i]);
         if (c->h_res[i]) (void)hipHostFree(c->h_res[i]);
@@ -1348,8 +1397,21 @@ extern "C" int orbx_stereo_match_batch_device_noalloc(orbx_ctx* c, int n_pairs, 
     scr.meta = (StereoMeta*)(base + rows_b);
     scr.wmax = (int32_t*)(base + rows_b + meta_b);
     scr.sad = (int32_t*)(base + rows_b + meta_b + wmax_b);
-    rc = run_stereo(c, c, n_pairs, 0, 1, 2, d_kps, d_kps + kp_cap, d_desc, d_desc + (size_t)kp_cap * 32, d_n, d_n + 1,
-                    2 * (int64_t)kp_cap, 2, kp_cap, mb, mbf, d_u_right, d_depth, scr);
+    {
+        // one user of the array at a time on this GPU: behind the previous user's kernels, whichever context ran them
+        const int dev = c->prm.device_id;
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (g_scratch_used[dev]) HIP_TRY(c, hipStreamWaitEvent(c->stream, g_scratch_event[dev], 0));
+        rc = run_stereo(c, c, n_pairs, 0, 1, 2, d_kps, d_kps + kp_cap, d_desc, d_desc + (size_t)kp_cap * 32, d_n, d_n + 1,
+                        2 * (int64_t)kp_cap, 2, kp_cap, mb, mbf, d_u_right, d_depth, scr);
+        // recorded even after a failed launch: whatever did get enqueued must be waited for
+        const hipError_t e_rec = hipEventRecord(g_scratch_event[dev], c->stream);
+        if (e_rec == hipSuccess) g_scratch_used[dev] = true;
+        if (rc == ORBX_OK && e_rec != hipSuccess) {
+            c->last_hip = (int)e_rec;
+            rc = ORBX_E_HIP;
+        }
+    }
     if (rc) return rc;
     if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
     return ORBX_OK;
@@ -2111,6 +2173,7 @@ extern "C" int orbx_set_debug_flag(orbx_ctx* c, int flag, int value) {
         case ORBX_FLAG_NO_GRAPH: c->dbg_no_graph = value != 0; break;
         case ORBX_FLAG_PIPE_CHUNK: c->dbg_pipe_chunk = std::max(0, value); break;
         case ORBX_FLAG_INIT_LIST: c->dbg_init_list = std::max(0, std::min(value, kInitListCap)); break;
+        case ORBX_FLAG_POISON: c->dbg_poison = (value >= 0 && value <= 3) ? value : 0; break;
         default: return ORBX_E_INVALID;
     }
     drop_graph(c);  // captured with the old switches
@@ -2160,6 +2223,7 @@ extern "C" const char* orbx_strerror(int code) {
         case ORBX_E_CAPACITY: return "capacity exceeded";
         case ORBX_E_GEOMETRY: return "image geometry not supported";
         case ORBX_E_STATE: return "no extraction has run";
+        case ORBX_E_DEVICE_DATA: return "a count or coordinate read on the device was out of bounds (results of that batch are invalid)";
         default: return "unknown error";
     }
 }

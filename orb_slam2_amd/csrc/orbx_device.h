@@ -31,6 +31,11 @@ struct __attribute__((packed, aligned(1))) uint4_unaligned {
     __device__ operator uint4() const { return make_uint4(x, y, z, w); }
 };
 
+// Words of BatchDev::status.  A kernel that reads a count or a coordinate out of device memory checks it against the
+// capacity it indexes, works on with the value cut to that capacity and sets the word; the host reports the batch as
+// failed (ORBX_E_DEVICE_DATA) at its next synchronisation instead of the GPU faulting on the access.
+enum { kStatusCellCount = 0, kStatusPoint = 1, kStatusLevelCount = 2, kStatusWords = 4 };
+
 // Per-level view used by every kernel.  Images of one level for all frames of the batch are
 // contiguous: frame f of level l starts at img + f*plane, rows `pitch` bytes apart.
 struct LevelDev {
@@ -64,6 +69,7 @@ struct BatchDev {
     int32_t kp_total;      // retained points per frame over all levels (sum of max_kp)
     int32_t ini_th, min_th;
     unsigned long long* stamps;  // cycle sums per phase, diagnostic builds only (null otherwise)
+    uint32_t* status;            // kStatus* words (host memory the device can write): non-zero = a kernel met a value outside its bounds
     int32_t pad0;
     int32_t blur_first[ORBX_MAX_LEVELS + 1];  // first blur block of each level; [nlevels] = total
 };

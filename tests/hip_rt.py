@@ -15,6 +15,7 @@ def rt():
         L.hipFree.argtypes = [C.c_void_p]
         L.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         L.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        L.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         _rt = L
     return _rt
 
@@ -48,3 +49,10 @@ class DeviceArray:
         if self.ptr:
             rt().hipFree(self.ptr)
             self.ptr = None
+
+
+def free_device_bytes():
+    """Free device memory as the runtime reports it (hipMemGetInfo)."""
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    assert rt().hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value

@@ -178,3 +178,29 @@ def test_bow_match_arguments(oracle):
     with pytest.raises(oa.OrbxError):
         ex.search_by_bow_batch_device(1, 0, 1, 1, 1, 1, 1, 100, 1, 1, 1, 1, 1, 100, 0.7, 1, 1, 1)     # null FeatureVector
     ex.close()
+
+
+def test_bow_match_oversized_counts_are_cut_to_the_capacity(oracle):
+    """FeatureVector counts above the arrays' capacity (a caller's mistake) are read as the capacity: the result equals
+    the oracle's on full arrays, and pair 0's search does not run on into pair 1's slice."""
+    rng = np.random.default_rng(9)
+    cap, n_nodes = 256, 8
+    ex = oa.ORBextractor(500, 1.2, 4, 20, 7, max_width=320, max_height=240, max_batch=2, keep_pyramid=False)
+    sides = []
+    for p in range(2):
+        desc_f = rng.integers(0, 256, (cap, 32), dtype=np.uint8)
+        desc_kf = desc_f[rng.integers(0, cap, cap)].copy()
+        desc_kf[np.arange(cap), rng.integers(0, 32, cap)] ^= 1
+        f_side, kf_side = list(made_up_side(rng, cap, cap, n_nodes, desc_f)), list(made_up_side(rng, cap, cap, n_nodes, desc_kf))
+        for s in (f_side, kf_side):   # fill the arrays to the brim: every feature is in the FeatureVector
+            node_of = rng.integers(1, n_nodes + 1, cap).astype(np.uint32)
+            order = np.lexsort((np.arange(cap), node_of))
+            s[0], s[1], s[2] = node_of[order], order.astype(np.uint32), np.int32(cap)
+        sides.append((tuple(kf_side) + (np.ones(cap, np.uint8),), tuple(f_side)))
+    kf = tuple(np.stack([sides[p][0][i] for p in range(2)]) for i in range(6))
+    f = tuple(np.stack([sides[p][1][i] for p in range(2)]) for i in range(5))
+    big_kf = kf[:2] + (np.array([cap + 1000, 2 ** 30], np.int32),) + kf[3:]
+    big_f = f[:2] + (np.array([2 ** 31 - 1, cap + 1], np.int32),) + f[3:]
+    match, nm = run_device(ex, big_kf, big_f, 0.75, True)
+    assert check_against_oracle(oracle, kf, f, [cap, cap], 0.75, True, match, nm) > 10
+    ex.close()

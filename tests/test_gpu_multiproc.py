@@ -95,3 +95,23 @@ def test_bench_two_rank_stream_rehearsal():
     assert b["config"]["frames_per_step_per_gpu"] == 4096
     assert b["value"] > 1000 and abs(b["value"] - 8192 / (b["ms_per_step"] * 1e-3)) < 1e-6 * b["value"]
     assert 1195 <= b["config"]["keypoints_per_frame"] <= 1230
+
+
+def test_bench_starts_its_own_ranks():
+    """`bench.py --gpus 2` with no launcher and no WORLD_SIZE: it starts the two ranks itself (sharing the one device
+    here, gloo for the scalars) and rank 0's line says n_gpus 2; with the RCCL backend and one device it refuses."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--pairs", "16", "--steps", "3", "--warmup",
+                          "1", "--no-cpu", "--no-extras"], env=dict(env, ORBX_BENCH_BACKEND="gloo"), cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # rank 0 alone prints
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["scaling"] == "weak" and b["config"]["frames_per_step_per_gpu"] == 32
+    assert abs(b["value"] - 2 * 32 / (b["ms_per_step"] * 1e-3)) < 1e-6 * b["value"]
+    import torch
+    if torch.cuda.device_count() < 2:           # more ranks than devices over RCCL: an error, never a smaller run
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--no-cpu",
+                              "--no-extras"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+        assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -1,6 +1,7 @@
 #!/bin/bash
 # The profile set of a round, on the GPU box through gpurun:  gpurun -- 'bash tools/round_profiles.sh r02'
 # Leaves gpurun_out/<tag>_{kernel_stats.csv,traffic.json,valu.json,pmc_sq.txt,bench.json}; copy them into profiles/.
+# BENCH_ARGS (environment) is added to every bench.py command (e.g. "--config c5"), BENCH_FINAL_ARGS to the last one only.
 # Every profiler pass is its own run of the same short benchmark (`bench.py --steps N --no-cpu --no-extras`).
 set -e
 TAG=${1:-rXX}
@@ -16,5 +17,5 @@ python3 tools/valu_summary.py $G/${TAG}_valu.json $G/pmc_${TAG}_sq/pmc_counter_c
 rm -rf $G/pmc_${TAG}_sq $G/pmc_${TAG}_sq2 $G/pmc_${TAG}_sq3 $G/pmc_${TAG}_sq*.txt
 # the bench line reads the counter summaries of the running sources from profiles/
 cp $G/${TAG}_traffic.json $G/${TAG}_valu.json profiles/
-timeout -k 10 900 python3 bench.py > $G/${TAG}_bench.json 2> $G/${TAG}_bench.err
+timeout -k 10 900 python3 bench.py $BENCH_ARGS $BENCH_FINAL_ARGS > $G/${TAG}_bench.json 2> $G/${TAG}_bench.err
 echo done

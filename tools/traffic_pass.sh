@@ -9,7 +9,7 @@ OUT=$PWD/gpurun_out/traffic_$TAG
 mkdir -p $OUT/rd $OUT/wr
 export TMPDIR=/tmp
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/rd -o pmc -- \
-    python3 bench.py --steps 2 --warmup 1 --no-cpu --no-extras > $OUT/rd/bench.log 2>&1
+    python3 bench.py --steps 2 --warmup 1 --no-cpu --no-extras $BENCH_ARGS > $OUT/rd/bench.log 2>&1
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/wr -o pmc -- \
-    python3 bench.py --steps 2 --warmup 1 --no-cpu --no-extras > $OUT/wr/bench.log 2>&1
+    python3 bench.py --steps 2 --warmup 1 --no-cpu --no-extras $BENCH_ARGS > $OUT/wr/bench.log 2>&1
 ls $OUT/rd $OUT/wr
