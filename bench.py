@@ -41,6 +41,8 @@ C2 = dict(name="c2", w=640, h=480, nfeat=1000, nlevels=8, config_id=1)    # TUM 
 C4 = dict(name="c4", w=752, h=480, nfeat=1200, nlevels=8, config_id=4)    # EuRoC (Examples/Stereo/EuRoC.yaml)
 C5 = dict(name="c5", w=3840, h=2160, nfeat=8000, nlevels=12, config_id=5)
 PAIRS = 256
+PROFILED_FRAMES = {"c3": 512, "c4": 512, "c5": 128}   # frames per step of the commands the counter files were collected on
+PROFILED_FRAMES_NOW = [512]
 C4_STREAM = 8192
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 STAGE_KERNEL = {"pyramid": "k_resize_rows", "fast": "k_fast_tiles", "quadtree": "k_octree", "blur": "k_blur7_all",
@@ -48,7 +50,15 @@ STAGE_KERNEL = {"pyramid": "k_resize_rows", "fast": "k_fast_tiles", "quadtree": 
 N_SIMD, VALU_CYCLES, CLOCK_HZ = 256 * 4, 4.0, 2.4e9  # a SIMD issues one wave64 vector instruction per 4 cycles
 
 
+COUNTER_PREFIX = ""   # "c5_" while the 4K configuration is the measured step: its counter files are profiles/rNN_c5_<kind>.json
+
+
 def counter_file(kind):
+    kind = COUNTER_PREFIX + kind
+    return _counter_file(kind)
+
+
+def _counter_file(kind):
     """The newest profiles/rNN_<kind>.json (counter passes of this same command, collected with
     tools/traffic_pass.sh / tools/pmc_multi.sh: counters cannot be read from inside the process).  A file
     made from other kernel sources than the ones loaded now is refused: its numbers describe other code."""
@@ -77,7 +87,7 @@ def measured_traffic(stage, frames_per_step, launches):
     if t is None:
         return None, src
     try:
-        return t[STAGE_KERNEL[stage]]["traffic_bytes"] / launches * frames_per_step / 512.0, src
+        return t[STAGE_KERNEL[stage]]["traffic_bytes"] / launches * frames_per_step / PROFILED_FRAMES_NOW[0], src
     except KeyError:
         return None, src
 
@@ -89,12 +99,36 @@ def valu_view(stage, frames_per_step, serial_ms):
     if t is None:
         return {"note": src}
     try:
-        instr = t[STAGE_KERNEL[stage]]["SQ_INSTS_VALU"] * frames_per_step / 512.0
+        instr = t[STAGE_KERNEL[stage]]["SQ_INSTS_VALU"] * frames_per_step / PROFILED_FRAMES_NOW[0]
     except KeyError:
         return {"note": src}
     floor_ms = instr * VALU_CYCLES / N_SIMD / CLOCK_HZ * 1e3
     return {"wave_instructions_per_step": instr, "issue_floor_ms": floor_ms, "serialised_ms": serial_ms,
             "frac_of_issue_ceiling": floor_ms / serial_ms if serial_ms > 0 else None, "source": src}
+
+
+def path_valu_view(frames_per_step, ms_per_step, frames_profiled):
+    """The whole step against the vector-issue ceiling, which is what bounds it: the five kernels' counted wave
+    instructions per step (SQ_INSTS_VALU) at one instruction per SIMD per 4 cycles, beside the measured step; and
+    per kernel the share of the LDS array's cycles lost to bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)."""
+    t, src = counter_file("valu")
+    if t is None:
+        return {"note": src}
+    per, lds, total = {}, {}, 0.0
+    for stage, kern in STAGE_KERNEL.items():
+        # a stage may run as more than one kernel (the pyramid of a single frame): every kernel of the file counts
+        names = [k for k in t if not k.startswith("_") and (k == kern or (stage == "pyramid" and k.startswith("k_resize")) or
+                                                            (stage == "quadtree" and k.startswith("k_octree")))]
+        v = sum(t[k].get("SQ_INSTS_VALU", 0.0) for k in names) * frames_per_step / frames_profiled
+        per[stage] = v
+        total += v
+        act = sum(t[k].get("SQ_LDS_IDX_ACTIVE", 0.0) for k in names)
+        lds[stage] = (sum(t[k].get("SQ_LDS_BANK_CONFLICT", 0.0) for k in names) / act) if act > 0 else 0.0
+    floor_ms = total * VALU_CYCLES / N_SIMD / CLOCK_HZ * 1e3
+    return {"wave_instructions_per_step": total, "per_kernel": per, "issue_floor_ms": floor_ms, "ms_per_step": ms_per_step,
+            "step_over_floor": ms_per_step / floor_ms if floor_ms > 0 else None, "lds_conflict_frac": lds, "source": src,
+            "note": "the step is bound by the sum of its kernels' vector instructions: floor = instructions x 4 cycles / 1024 "
+                    "SIMDs / 2.4 GHz; lds_conflict_frac = bank-conflict cycles / LDS array cycles per kernel"}
 
 
 def level_pixels(oa, cfg):
@@ -319,6 +353,38 @@ def rate_entry(oa, cfg, n, sec_per_step, counts, note):
             "keypoints_per_frame": kavg, "algorithmic_bytes_per_frame": b, "frac_of_hbm_peak": b * fps / 1e9 / HBM_PEAK_GBS}
 
 
+def stereo_pair_latency(pairs=300):
+    """One KITTI-shape stereo pair per call through the drop-in C++ class (tests/cpp/orbextractor_harness, built by
+    __graft_entry__.build()): the reference's pattern -- two instances, two threads created per pair, then the
+    association (src/Frame.cc:78-81, :90) -- beside the same on one thread and beside ExtractStereoPair, which is one
+    captured graph launch on one instance.  Median milliseconds per pair, pyramids not copied back."""
+    from orb_slam2_amd import synth
+    exe = os.path.join(ROOT, "tests", "cpp", "orbextractor_harness")
+    if not os.path.exists(exe):
+        return {"error": "tests/cpp/orbextractor_harness not built"}
+    w, h = C3["w"], C3["h"]
+    base = synth.make_batch(8, w + 32, h, config_id=3, first_idx=900)
+    fr = np.zeros((2 * pairs, h, w), np.uint8)
+    for p in range(pairs):
+        fr[2 * p], fr[2 * p + 1] = base[p % 8][:, :w], base[p % 8][:, 7:w + 7]
+    out = {"workload": "1241x376, 2000 features, 8 levels: host images in, keypoints, descriptors, mvuRight and mvDepth out, "
+                       "%d pairs, ORB_SLAM2::ORBextractor (C++ class) over the C ABI" % pairs}
+    with tempfile.TemporaryDirectory(prefix="orbx_pair_") as d:
+        raw = os.path.join(d, "pairs.raw")
+        fr.tofile(raw)
+        for key, mode in (("two_instances_two_threads", 1), ("two_instances_one_thread", 0), ("one_instance_one_graph", 2)):
+            try:
+                r = subprocess.run([exe, "threads", "2000", "1.2", "8", str(w), str(h), str(pairs), raw, "0.5371657", "386.1448",
+                                    os.path.join(d, "o.bin"), str(mode)], capture_output=True, text=True, timeout=300,
+                                   env=dict(os.environ, ORBX_KEEP_PYRAMID="0"))
+                m = re.search(r"pair_ms median ([0-9.]+) p10 ([0-9.]+) p90 ([0-9.]+)", r.stdout)
+                out[key] = ({"median": float(m.group(1)), "p10": float(m.group(2)), "p90": float(m.group(3))} if m else
+                            {"error": (r.stderr or r.stdout)[-300:]})
+            except Exception as e:
+                out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
 def extras(torch, oa, device):
     """The other configurations of the benchmark suite on this GPU, each with its own algorithmic-byte fraction."""
     out = {}
@@ -345,21 +411,33 @@ def extras(torch, oa, device):
                 for l, p in enumerate(pyr):
                     assert L.orbx_pyramid_level(ex._ctx, 0, l, p.ctypes.data_as(C.c_void_p), p.strides[0], None, None) == 0
 
+        def call_padded(i, _):
+            # mvImagePyramid for a host-side reader: the padded levels are built on the device inside the same submission
+            # and read in place from the context's pinned memory (orbx_set_keep_pyramid / orbx_padded_level)
+            call(i, False)
+            base, lw, lh, st = C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
+            for l in range(cfg["nlevels"]):
+                assert L.orbx_padded_level(ex._ctx, l, C.byref(base), C.byref(lw), C.byref(lh), C.byref(st)) == 0
+
         lat = {}
         for key, with_pyr, graph, reps in (("graph", False, 1, 1000), ("plain_launches", False, 0, 1000),
-                                           ("graph_with_pyramid_readback", True, 1, 1000)):
+                                           ("graph_with_pyramid_readback", True, 1, 1000),
+                                           ("graph_with_padded_pyramid", "padded", 1, 1000)):
             ex.set_debug_flag(oa.FLAG_NO_GRAPH, 0 if graph else 1)
+            assert L.orbx_set_keep_pyramid(ex._ctx, 19 if with_pyr == "padded" else 0) == 0
+            call_ = call_padded if with_pyr == "padded" else call
             for i in range(20):
-                call(i, with_pyr)
+                call_(i, with_pyr)
             t = []
             for i in range(reps):
                 t0 = time.perf_counter()
-                call(i, with_pyr)
+                call_(i, with_pyr)
                 t.append(time.perf_counter() - t0)
             t = np.array(t) * 1e3
             lat[key] = {"median": float(np.median(t)), "p10": float(np.percentile(t, 10)), "p90": float(np.percentile(t, 90)),
                         "calls": reps}
         ex.close()
+        lat["stereo_pair"] = stereo_pair_latency()
         out["latency_ms"] = dict(lat, workload="C2: one 640x480 frame per orbx_extract call, 1000 features, 8 levels: host image "
                                                "in, host keypoints + descriptors out (upload, whole path, download); 'graph' = "
                                                "one HIP graph launch per call (the default), 'plain_launches' = the same "
@@ -426,6 +504,55 @@ def host_to_host(oa, run):
     return e
 
 
+def host_stream(args):
+    """`--config c4 --host`: the EuRoC-shape stream of 8192 frames from pageable HOST memory through the in-process
+    worker pool (orbx_pool_*: one worker thread and one context per GPU, contiguous pair-aligned shards, pinned
+    rings, results gathered in frame order in host memory).  One process, N devices; PCIe both ways is inside the
+    timed region.  ORBX_POOL_DEVICES="0,0" lists the devices explicitly (a rehearsal with two workers on one GPU)."""
+    import torch
+    import orb_slam2_amd as oa
+    from orb_slam2_amd import synth
+    cfg = C4
+    if os.environ.get("ORBX_POOL_DEVICES"):
+        devices = [int(v) for v in os.environ["ORBX_POOL_DEVICES"].split(",")]
+    else:
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit("--gpus %d but this node has %d device(s)" % (args.gpus, torch.cuda.device_count()))
+        devices = list(range(args.gpus))
+    W, H = cfg["w"], cfg["h"]
+    base = synth.make_batch(64, W, H, config_id=cfg["config_id"], first_idx=3000)
+    frames = [np.array(base[i % 64]) for i in range(C4_STREAM)]      # 8192 separate pageable arrays (3 GB)
+    pool = oa.ExtractorPool(cfg["nfeat"], SCALE, cfg["nlevels"], INI_TH, MIN_TH, devices, max_width=W, max_height=H, max_batch=512)
+    out = None
+    for _ in range(max(1, min(args.warmup, 2))):
+        out = pool.extract_stream(frames, out)
+    t = []
+    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        out = pool.extract_stream(frames, out)
+        t.append(time.perf_counter() - t0)
+    dt = float(np.sum(t))
+    counts = out[2]
+    res = rate_entry(oa, cfg, C4_STREAM, dt / args.steps, counts, "EuRoC-shape stream")
+    line = {"metric": "ORB frames/sec (752x480 EuRoC stream of 8192 frames, 1200 kp, 8 lvl), host frames in, host results out",
+            "value": C4_STREAM * args.steps / dt, "unit": "frames/s", "n_gpus": len(set(devices)), "steps": args.steps,
+            "warmup": max(1, min(args.warmup, 2)), "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "EuRoC-shape stereo stream, %d frames of 752x480 in pageable host memory, 1200 features/image, 8 "
+                                   "levels, cut by frame over %d worker(s) on device(s) %s of ONE process; keypoints and descriptors "
+                                   "back in host memory in frame order (PCIe both ways inside the timed region)"
+                                   % (C4_STREAM, len(devices), devices),
+                       "workers": len(devices), "devices": devices, "keypoints_per_frame": res["keypoints_per_frame"],
+                       "parallelism": "in-process pool: one host worker thread and one context per GPU, no collective"},
+            "spread_ms": {"min": 1e3 * min(t), "median": 1e3 * float(np.median(t)), "max": 1e3 * max(t)},
+            "GBs_in": C4_STREAM * W * H * args.steps / dt / 1e9,
+            "path_roofline": {"algorithmic_bytes_per_frame": res["algorithmic_bytes_per_frame"],
+                              "frac_of_hbm_peak": res["frac_of_hbm_peak"] / max(1, len(set(devices)))},
+            "cpu_baseline": None}
+    pool.close()
+    print(json.dumps(line))
+
+
 def self_launch(n):
     """`bench.py --gpus N` started without a launcher (no WORLD_SIZE in the environment): starts the N ranks as fresh
     child processes -- one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set per child, the same command line --
@@ -473,7 +600,15 @@ def main():
     ap.add_argument("--config", choices=("c3", "c4", "c5"), default="c3")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the other configurations and the consumers")
+    ap.add_argument("--host", action="store_true",
+                    help="with --config c4: host frames in, host results out, through the in-process worker pool over --gpus devices")
     args = ap.parse_args()
+    if args.host:
+        if args.config != "c4":
+            raise SystemExit("--host goes with --config c4")
+        if args.steps == 500:
+            args.steps = 5      # a step is the whole 8192-frame stream over PCIe: about 0.1 s
+        return host_stream(args)
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
@@ -522,6 +657,9 @@ def main():
         workload = ("KITTI stereo 1241x376 left+right, 2000 features/image, 8 levels, scale 1.2, FAST 20/7, %d pairs (%d frames) "
                     "per step per GPU, frames resident in HBM" % (args.pairs, n))
     elif args.config == "c5":
+        global COUNTER_PREFIX
+        COUNTER_PREFIX = "c5_"
+        PROFILED_FRAMES_NOW[0] = PROFILED_FRAMES["c5"]
         # the 4K configuration as the measured step (profiles of its kernels); `extras` reports the same step
         cfg, n = C5, min(128, 2 * args.pairs)
         run = DeviceRun(torch, oa, cfg, n, local_rank, first_idx=2000 + rank, n_base=2)
@@ -666,6 +804,7 @@ def main():
             "roofline": roof,
             "path_roofline": {"algorithmic_bytes_per_frame": b_frame, "achieved_GBs_per_gpu": b_frame * fps / world / 1e9,
                               "frac_of_hbm_peak": b_frame * fps / world / 1e9 / HBM_PEAK_GBS},
+            "path_valu_issue": path_valu_view(n, 1000.0 * dt / args.steps, PROFILED_FRAMES[args.config]),
             "stage_ms": stage_ms, "stage_ms_serialised": serial_sum,
             "next_stage": next_stage, "next_stage_matching": proj, "host_to_host": h2h,
         }

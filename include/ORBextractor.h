@@ -14,6 +14,9 @@
  *  - environment: ORBX_DEVICE selects the HIP device ordinal (default 0);
  *    ORBX_KEEP_PYRAMID=0 skips the device-to-host copy that keeps mvImagePyramid valid (only
  *    stereo matching reads it, reference src/Frame.cc:492-599);
+ *  - the matrices in mvImagePyramid are headers over memory the instance owns and refills on every
+ *    call (the reference allocates new buffers per call): a cv::Mat copied out of the member shows the
+ *    next image after the next call -- clone() it to keep it;
  *  - a GPU failure is fatal (message on stderr, abort): the reference API has no error channel
  *    and there is deliberately no CPU fallback.
  */
@@ -74,6 +77,16 @@ public:
     void ComputeStereoMatches(ORBextractor& right, float mb, float mbf, std::vector<float>& vuRight,
                               std::vector<float>& vDepth);
 
+    // Extension, not in the reference header: what the stereo Frame constructor does with two extractor
+    // instances on two threads and the association behind them (reference src/Frame.cc:78-81, :90), as ONE
+    // call on this one instance and one submission to the GPU: both images are extracted in the same
+    // launches and Frame::ComputeStereoMatches follows on the device.  Outputs as operator() gives them per
+    // image, plus mvuRight / mvDepth of the left keypoints.  mvImagePyramid is not touched (nothing reads it
+    // once the association runs on the device).
+    void ExtractStereoPair(cv::InputArray imLeft, cv::InputArray imRight, std::vector<cv::KeyPoint>& keysLeft,
+                           cv::OutputArray descLeft, std::vector<cv::KeyPoint>& keysRight, cv::OutputArray descRight,
+                           float mb, float mbf, std::vector<float>& vuRight, std::vector<float>& vDepth);
+
 protected:
     int nfeatures;
     double scaleFactor;
@@ -92,6 +105,9 @@ private:
     ORBextractor(const ORBextractor&);
     ORBextractor& operator=(const ORBextractor&);
     void EnsureContext(int width, int height);
+    int EnsureBuffers(int width, int height, int frames);
+
+    std::vector<unsigned char> mvKpBuf, mvDescBuf;  // results as the library writes them, kept across calls
 
     orbx_ctx* mpCtx;
     int mnCtxWidth, mnCtxHeight;    // size the device context was created for

@@ -106,6 +106,13 @@ uint32_t orbx_host_blur_rim_selector(int target_col, int hi_col, int lo_col, int
 /* Upper bound on keypoints returned per image for these parameters and image size. */
 int orbx_host_max_keypoints(int nfeatures, float scale_factor, int nlevels, int width, int height);
 
+/* The frames [*first, *last) that worker `rank` of `world` takes of a stream of n_frames frames: contiguous runs
+ * of stereo pairs (frames 2k, 2k + 1 stay together, so that the association of src/Frame.cc:90 can follow on the
+ * same device), sizes differing by at most one pair.  The multi-GPU paths (orbx_pool_extract_stream, the
+ * process-per-GPU benchmark) cut their streams with it; the reference has one extractor per image and no
+ * counterpart (src/Frame.cc:78-81). */
+int orbx_host_frame_shard(int n_frames, int rank, int world, int* first, int* last);
+
 /* ---- context -------------------------------------------------------------------------- */
 
 /* Replaces `new ORBextractor(...)` (reference src/Tracking.cc:121,125,128). */
@@ -128,11 +135,43 @@ void orbx_destroy(orbx_ctx* ctx);
 int orbx_extract(orbx_ctx* ctx, const uint8_t* img, int width, int height, int stride,
                  orbx_kp* kps, int kp_cap, uint8_t* desc, int* n_out);
 
+/* A stereo pair in host memory as ONE call on ONE context.  Replaces what the stereo Frame constructor does with
+ * its two extractor instances on two threads plus the association that follows (reference src/Frame.cc:78-81:
+ * thread threadLeft(&Frame::ExtractORB, this, 0, imLeft), threadRight(..., 1, imRight), join; :90
+ * ComputeStereoMatches): both images go through the extractor in the same launches (frame 0 = left, 1 = right),
+ * the stereo association of orbx_stereo_match runs behind them on the device, and upload, all launches and the
+ * downloads are one captured HIP graph per image size, replayed per call.  kps[2 * kp_cap], desc[2 * kp_cap * 32]
+ * and n_out[2] are laid out as orbx_extract_batch lays out two frames; u_right[kp_cap] and depth[kp_cap] receive
+ * mvuRight and mvDepth of the n_out[0] left keypoints (-1 = no match), or pass both NULL to skip the
+ * association (mb, mbf are then ignored; else mb = baseline in metres, mbf = baseline * fx, src/Frame.cc:114).
+ * The context must have been created with max_batch >= 2.  The pyramids of both images stay readable
+ * (orbx_pyramid_level, image 0 and 1). */
+int orbx_extract_pair(orbx_ctx* ctx, const uint8_t* left, int stride_left, const uint8_t* right, int stride_right,
+                      int width, int height, orbx_kp* kps, int kp_cap, uint8_t* desc, int n_out[2], float mb, float mbf,
+                      float* u_right, float* depth);
+
 /* n images of one size in host memory; image i starts at imgs[i] with row stride strides[i].
  * kps[n*kp_cap], desc[n*kp_cap*32], n_out[n].  The throughput entry point: the reference
  * processes one image per call (src/Frame.cc:249-255); batching has no counterpart there. */
 int orbx_extract_batch(orbx_ctx* ctx, int n, const uint8_t* const* imgs, int width, int height,
                        const int* strides, orbx_kp* kps, int kp_cap, uint8_t* desc, int* n_out);
+
+/* ---- several GPUs in one process: a pool of workers -----------------------------------------
+ * One host worker thread and one context per entry of devices[] (a device may be listed more than once: its
+ * workers then share it).  params as for orbx_create (device_id is ignored; max_batch >= 2 is the number of frames a
+ * worker hands its GPU per orbx_extract_batch call).  orbx_pool_extract_stream is orbx_extract_batch for a stream
+ * of n host frames over all workers: worker r takes the frames orbx_host_frame_shard(n, r, workers) names, runs
+ * them through its context's chunked, pipelined host path (pinned upload and result slots, copies overlapped with
+ * the kernels) and writes their results into the caller's arrays at the frames' own positions, so that kps, desc
+ * and n_out are in frame order when the call returns.  No data crosses devices.  Returns the first error of any
+ * worker (the arrays are then not to be used).  Has no counterpart in the reference, which extracts one image per
+ * call on the calling thread (src/Frame.cc:249-255); it is the in-process form of sharding a stream by frame. */
+typedef struct orbx_pool orbx_pool;
+int orbx_pool_create(const orbx_params* params, const int* devices, int n_workers, orbx_pool** out);
+void orbx_pool_destroy(orbx_pool* pool);
+int orbx_pool_workers(const orbx_pool* pool);
+int orbx_pool_extract_stream(orbx_pool* pool, int n, const uint8_t* const* imgs, int width, int height,
+                             const int* strides, orbx_kp* kps, int kp_cap, uint8_t* desc, int* n_out);
 
 /* As orbx_extract_batch with every buffer already in device memory (HBM-resident input,
  * HBM-resident results).  d_imgs holds n images, image i at d_imgs + i*frame_stride, rows
@@ -588,6 +627,19 @@ int orbx_stereo_match_batch_device_noalloc(orbx_ctx* ctx, int n_pairs, const orb
  * (reference include/ORBextractor.h:85; read by src/Frame.cc:492,582,594,599). */
 int orbx_pyramid_level(orbx_ctx* ctx, int img_idx, int level, uint8_t* dst, int dst_stride,
                        int* width, int* height);
+
+/* mvImagePyramid as ComputePyramid leaves it (reference src/ORBextractor.cc:1227-1245: every level is the ROI at
+ * (border, border) of a buffer with a `border`-pixel BORDER_REFLECT_101 rim, EDGE_THRESHOLD = 19 there), for callers
+ * that read the public member on the host (the reference's own Frame::ComputeStereoMatches, src/Frame.cc:582-599).
+ * orbx_set_keep_pyramid(ctx, border > 0): from now on every single-image extraction (orbx_extract, orbx_extract_batch
+ * with n = 1) also builds the padded levels on the device and copies them, inside the same submission, into pinned
+ * host memory the context owns; border = 0 switches that off again (the default).  orbx_padded_level then gives the
+ * address of padded level `level` of the last such extraction: *base points at the buffer's first byte (the rim's
+ * corner), rows are *stride = width + 2 * border bytes apart, the level itself starts at base + border * stride +
+ * border.  The memory stays valid and unchanged until the next extraction, orbx_set_keep_pyramid or orbx_destroy on
+ * the context: read it in place (no copy), or copy it out if it must outlive the next call. */
+int orbx_set_keep_pyramid(orbx_ctx* ctx, int border);
+int orbx_padded_level(orbx_ctx* ctx, int level, const uint8_t** base, int* width, int* height, int* stride);
 
 /* ---- introspection for tests and measurement ------------------------------------------- */
 

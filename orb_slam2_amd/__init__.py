@@ -62,6 +62,8 @@ EXPORTS = [
     "orbx_fuse_search_batch_device", "orbx_search_guided_batch_device", "orbx_bow_score_l1_batch_device",
     "orbx_is_in_frustum_batch_device", "orbx_fuse_project_batch_device", "orbx_project_guided_batch_device",
     "orbx_sim3_project_batch_device",
+    "orbx_extract_pair", "orbx_set_keep_pyramid", "orbx_padded_level",
+    "orbx_host_frame_shard", "orbx_pool_create", "orbx_pool_destroy", "orbx_pool_workers", "orbx_pool_extract_stream",
 ]
 
 _lib = None
@@ -126,6 +128,15 @@ def load_library():
     L.orbx_remap_batch_device.argtypes = [vp, i32, vp, i32, i32, i32, C.c_size_t, vp, vp, i32, vp, i32, i32, i32,
                                           C.c_size_t, i32]
     L.orbx_pyramid_level.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.orbx_extract_pair.argtypes = [vp, vp, i32, vp, i32, i32, i32, vp, i32, vp, vp, f32, f32, vp, vp]
+    L.orbx_set_keep_pyramid.argtypes = [vp, i32]
+    L.orbx_host_frame_shard.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.orbx_pool_create.argtypes = [C.POINTER(_Params), vp, i32, C.POINTER(vp)]
+    L.orbx_pool_destroy.argtypes = [vp]
+    L.orbx_pool_destroy.restype = None
+    L.orbx_pool_workers.argtypes = [vp]
+    L.orbx_pool_extract_stream.argtypes = [vp, i32, vp, i32, i32, vp, vp, i32, vp, vp]
+    L.orbx_padded_level.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.orbx_debug_read.argtypes = [vp, i32, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.orbx_set_profiling.argtypes = [vp, i32]
     L.orbx_set_debug_flag.argtypes = [vp, i32, i32]
@@ -200,6 +211,57 @@ def host_max_keypoints(nfeatures, scale_factor, nlevels, width, height):
     return rc
 
 
+def host_frame_shard(n_frames, rank, world):
+    """[first, last) of worker `rank` of `world` (orbx_host_frame_shard: contiguous runs of stereo pairs)."""
+    a, b = C.c_int(0), C.c_int(0)
+    _check(load_library().orbx_host_frame_shard(n_frames, rank, world, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+class ExtractorPool:
+    """Several GPUs in one process (orbx_pool_*): one worker thread and one context per listed device; a stream of
+    host frames is cut by frame into pair-aligned shards, results come back in frame order."""
+
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, devices, *, max_width, max_height, max_batch=256):
+        self._pool = None
+        L = load_library()
+        self._L = L
+        self.nfeatures, self.nlevels, self.scaleFactor = int(nfeatures), int(nlevels), float(np.float32(scaleFactor))
+        p = _Params(self.nfeatures, self.scaleFactor, self.nlevels, int(iniThFAST), int(minThFAST), 0, max_width, max_height,
+                    max_batch, 0)
+        dev = np.asarray(list(devices), np.int32)
+        pool = C.c_void_p()
+        _check(L.orbx_pool_create(C.byref(p), _ptr(dev), len(dev), C.byref(pool)))
+        self._pool = pool
+
+    def workers(self):
+        return self._L.orbx_pool_workers(self._pool)
+
+    def extract_stream(self, images, out=None):
+        """images: list of equally sized 2-D uint8 arrays.  Returns (kps [n][cap], desc [n][cap][32], counts [n]);
+        `out` = such a triple to reuse."""
+        n = len(images)
+        h, w = images[0].shape
+        cap = host_max_keypoints(self.nfeatures, self.scaleFactor, self.nlevels, w, h)
+        kps, desc, cnt = out if out is not None else (np.zeros((n, cap), KP_DTYPE), np.zeros((n, cap, 32), np.uint8),
+                                                      np.zeros(n, np.int32))
+        ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in images])
+        strides = np.array([im.strides[0] for im in images], np.int32)
+        _check(self._L.orbx_pool_extract_stream(self._pool, n, ptrs, w, h, _ptr(strides), _ptr(kps), cap, _ptr(desc), _ptr(cnt)))
+        return kps, desc, cnt
+
+    def close(self):
+        if self._pool is not None:
+            self._L.orbx_pool_destroy(self._pool)
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ORBextractor:
     """Mirror of ORB_SLAM2::ORBextractor on the MI355X.
 
@@ -228,6 +290,8 @@ class ORBextractor:
         self._ctx = ctx
         self._max = (max_width, max_height, max_batch)
         self._size = (max_width, max_height)
+        if keep_pyramid:   # the padded pyramid is built on the device and copied inside the extraction's own submission
+            _check(L.orbx_set_keep_pyramid(ctx, EDGE_THRESHOLD), ctx)
 
     def close(self):
         if self._ctx is not None:
@@ -286,8 +350,40 @@ class ORBextractor:
         _check(self._L.orbx_extract(self._ctx, _ptr(image), w, h, image.strides[0], _ptr(kps), cap, _ptr(desc),
                                     C.byref(n)), self._ctx)
         if self.keep_pyramid:
-            self.mvImagePyramid = [self.pyramid_level(0, l, padded=True) for l in range(self.nlevels)]
+            self.mvImagePyramid = [self.padded_level(l) for l in range(self.nlevels)]
         return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def padded_level(self, level, copy=True):
+        """Level `level` of the last single-image extraction as the reference keeps it in mvImagePyramid: the un-padded
+        ROI of a buffer with a 19-px reflect-101 border (src/ORBextractor.cc:1227-1245), built on the device.  copy=False
+        returns a view of the context's pinned memory, valid until the next extraction."""
+        base, w, h, st = C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
+        _check(self._L.orbx_padded_level(self._ctx, level, C.byref(base), C.byref(w), C.byref(h), C.byref(st)), self._ctx)
+        E = EDGE_THRESHOLD
+        raw = (C.c_uint8 * (st.value * (h.value + 2 * E))).from_address(base.value)
+        buf = np.frombuffer(raw, np.uint8).reshape(h.value + 2 * E, st.value)
+        if copy:
+            buf = buf.copy()
+        return buf[E:E + h.value, E:E + w.value]
+
+    def extract_pair(self, left, right, mb=None, mbf=None):
+        """A stereo pair through one context as one call (orbx_extract_pair: what the stereo Frame constructor does
+        with two extractor instances on two threads and ComputeStereoMatches, src/Frame.cc:78-81, 90).  Returns
+        ((kps_l, desc_l), (kps_r, desc_r), u_right, depth); the last two are None when mb is None."""
+        left, right = np.ascontiguousarray(left), np.ascontiguousarray(right)
+        if left.dtype != np.uint8 or left.ndim != 2 or right.dtype != np.uint8 or right.shape != left.shape:
+            raise OrbxError("pair images must be 8-bit single channel and equally sized")
+        h, w = left.shape
+        self._size = (w, h)
+        cap = self.max_keypoints(w, h)
+        kps, desc, n = np.zeros((2, cap), KP_DTYPE), np.zeros((2, cap, 32), np.uint8), np.zeros(2, np.int32)
+        stereo = mb is not None
+        u, d = (np.full(cap, -1, np.float32), np.full(cap, -1, np.float32)) if stereo else (None, None)
+        _check(self._L.orbx_extract_pair(self._ctx, _ptr(left), left.strides[0], _ptr(right), right.strides[0], w, h, _ptr(kps),
+                                         cap, _ptr(desc), _ptr(n), float(mb or 0), float(mbf or 0),
+                                         _ptr(u) if stereo else None, _ptr(d) if stereo else None), self._ctx)
+        out = [(kps[i, :n[i]].copy(), desc[i, :n[i]].copy()) for i in range(2)]
+        return out[0], out[1], (u[:n[0]] if stereo else None), (d[:n[0]] if stereo else None)
 
     def extract_batch(self, images):
         """images: (n, h, w) uint8 array or list of equally sized 2-D arrays, host memory."""

@@ -21,10 +21,31 @@ void Fatal(const char* what, int code, const orbx_ctx* ctx) {
     std::abort();
 }
 
-inline int Reflect101(int p, int len) {
-    if (p < 0) p = -p;
-    if (p >= len) p = 2 * len - 2 - p;
-    return p;
+void FillKeyPoints(const orbx_kp* kps, int n, std::vector<cv::KeyPoint>& out) {
+    out.resize((size_t)n);
+    for (int i = 0; i < n; i++) {
+        cv::KeyPoint& k = out[(size_t)i];
+        k.pt.x = kps[i].x;
+        k.pt.y = kps[i].y;
+        k.size = kps[i].size;
+        k.angle = kps[i].angle;
+        k.response = kps[i].response;
+        k.octave = kps[i].octave;
+        k.class_id = kps[i].class_id;
+    }
+}
+
+void FillDescriptors(const unsigned char* desc, int n, cv::OutputArray out) {
+    if (n == 0) {
+        out.release();  // reference :1160-1161
+        return;
+    }
+    out.create(n, 32, CV_8U);
+    cv::Mat d = out.getMat();
+    if (d.isContinuous())
+        std::memcpy(d.data, desc, (size_t)n * 32);
+    else
+        for (int i = 0; i < n; i++) std::memcpy(d.ptr(i), desc + (size_t)i * 32, 32);
 }
 }  // namespace
 
@@ -69,11 +90,22 @@ void ORBextractor::EnsureContext(int width, int height) {
     p.device_id = mnDevice;
     p.max_width = width > mnCtxWidth ? width : mnCtxWidth;
     p.max_height = height > mnCtxHeight ? height : mnCtxHeight;
-    p.max_batch = 1;
+    p.max_batch = 2;  // a stereo pair through one instance (ExtractStereoPair)
     int rc = orbx_create(&p, &mpCtx);
     if (rc != ORBX_OK) Fatal("orbx_create", rc, NULL);
     mnCtxWidth = p.max_width;
     mnCtxHeight = p.max_height;
+    // mvImagePyramid with its 19-pixel border is built on the device and arrives with the keypoints
+    if (mbKeepPyramid && (rc = orbx_set_keep_pyramid(mpCtx, EDGE_THRESHOLD)) != ORBX_OK) Fatal("orbx_set_keep_pyramid", rc, mpCtx);
+}
+
+// Result buffers sized for the image, kept across calls.
+int ORBextractor::EnsureBuffers(int width, int height, int frames) {
+    const int cap = orbx_host_max_keypoints(nfeatures, (float)scaleFactor, nlevels, width, height);
+    if (cap < 0) Fatal("orbx_host_max_keypoints", cap, mpCtx);
+    if (mvKpBuf.size() < (size_t)cap * 28 * frames) mvKpBuf.resize((size_t)cap * 28 * frames);
+    if (mvDescBuf.size() < (size_t)cap * 32 * frames) mvDescBuf.resize((size_t)cap * 32 * frames);
+    return cap;
 }
 
 // Reference src/ORBextractor.cc:1137-1211.
@@ -88,59 +120,58 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     EnsureContext(image.cols, image.rows);
     mnLastWidth = image.cols;
     mnLastHeight = image.rows;
-    const int cap = orbx_host_max_keypoints(nfeatures, (float)scaleFactor, nlevels, image.cols, image.rows);
-    if (cap < 0) Fatal("orbx_host_max_keypoints", cap, mpCtx);
-    std::vector<orbx_kp> kps(cap);
-    std::vector<unsigned char> desc((size_t)cap * 32);
+    const int cap = EnsureBuffers(image.cols, image.rows, 1);
+    orbx_kp* kps = reinterpret_cast<orbx_kp*>(&mvKpBuf[0]);
     int n = 0;
-    int rc = orbx_extract(mpCtx, image.data, image.cols, image.rows, (int)image.step, &kps[0], cap, &desc[0], &n);
+    int rc = orbx_extract(mpCtx, image.data, image.cols, image.rows, (int)image.step, kps, cap, &mvDescBuf[0], &n);
     if (rc != ORBX_OK) Fatal("orbx_extract", rc, mpCtx);
+    FillDescriptors(&mvDescBuf[0], n, _descriptors);
+    FillKeyPoints(kps, n, _keypoints);
 
-    if (n == 0)
-        _descriptors.release();
-    else {
-        _descriptors.create(n, 32, CV_8U);
-        cv::Mat d = _descriptors.getMat();
-        for (int i = 0; i < n; i++) std::memcpy(d.ptr(i), &desc[(size_t)i * 32], 32);
-    }
-    _keypoints.clear();
-    _keypoints.reserve(n);
-    for (int i = 0; i < n; i++) {
-        cv::KeyPoint k;
-        k.pt.x = kps[i].x;
-        k.pt.y = kps[i].y;
-        k.size = kps[i].size;
-        k.angle = kps[i].angle;
-        k.response = kps[i].response;
-        k.octave = kps[i].octave;
-        k.class_id = kps[i].class_id;
-        _keypoints.push_back(k);
-    }
-
-    // mvImagePyramid as ComputePyramid leaves it (reference :1213-1250): each level is the ROI at
-    // (19,19) of a buffer carrying a 19-pixel reflect-101 border.
+    // mvImagePyramid as ComputePyramid leaves it (reference :1213-1250): each level is the ROI at (19,19) of a
+    // buffer carrying a 19-pixel reflect-101 border.  The buffers are the context's pinned memory, filled by the
+    // extraction's own submission: the matrices below are headers over it (no copy) and show this image's pyramid
+    // until the next call of this instance -- as in the reference, where the next call replaces the member.
     if (mbKeepPyramid) {
         for (int level = 0; level < nlevels; ++level) {
-            orbx_level_geom g;
-            rc = orbx_host_level_geometry(nfeatures, (float)scaleFactor, nlevels, image.cols, image.rows, level, &g);
-            if (rc != ORBX_OK) Fatal("orbx_host_level_geometry", rc, mpCtx);
-            cv::Mat temp(g.height + 2 * EDGE_THRESHOLD, g.width + 2 * EDGE_THRESHOLD, CV_8UC1);
-            cv::Mat roi = temp(cv::Rect(EDGE_THRESHOLD, EDGE_THRESHOLD, g.width, g.height));
-            int w = 0, h = 0;
-            rc = orbx_pyramid_level(mpCtx, 0, level, roi.data, (int)roi.step, &w, &h);
-            if (rc != ORBX_OK) Fatal("orbx_pyramid_level", rc, mpCtx);
-            for (int y = -EDGE_THRESHOLD; y < h + EDGE_THRESHOLD; y++) {
-                unsigned char* drow = temp.ptr(y + EDGE_THRESHOLD);
-                const unsigned char* srow = roi.ptr(Reflect101(y, h));
-                if (y < 0 || y >= h) std::memcpy(drow + EDGE_THRESHOLD, srow, w);
-                for (int x = 1; x <= EDGE_THRESHOLD; x++) {
-                    drow[EDGE_THRESHOLD - x] = srow[Reflect101(-x, w)];
-                    drow[EDGE_THRESHOLD + w - 1 + x] = srow[Reflect101(w - 1 + x, w)];
-                }
-            }
-            mvImagePyramid[level] = roi;
+            const unsigned char* base = NULL;
+            int w = 0, h = 0, stride = 0;
+            rc = orbx_padded_level(mpCtx, level, &base, &w, &h, &stride);
+            if (rc != ORBX_OK) Fatal("orbx_padded_level", rc, mpCtx);
+            cv::Mat temp(h + 2 * EDGE_THRESHOLD, w + 2 * EDGE_THRESHOLD, CV_8UC1, const_cast<unsigned char*>(base), (size_t)stride);
+            mvImagePyramid[level] = temp(cv::Rect(EDGE_THRESHOLD, EDGE_THRESHOLD, w, h));
         }
     }
+}
+
+// Extension: both images of a stereo pair through this one instance, with the stereo association, as one call
+// (orbx_extract_pair).  Stands for reference src/Frame.cc:78-81 and :90.
+void ORBextractor::ExtractStereoPair(cv::InputArray _left, cv::InputArray _right, std::vector<cv::KeyPoint>& keysLeft,
+                                     cv::OutputArray descLeft, std::vector<cv::KeyPoint>& keysRight, cv::OutputArray descRight,
+                                     float mb, float mbf, std::vector<float>& vuRight, std::vector<float>& vDepth) {
+    if (_left.empty() || _right.empty()) return;
+    cv::Mat left = _left.getMat(), right = _right.getMat();
+    if (left.type() != CV_8UC1 || right.type() != CV_8UC1 || left.size() != right.size()) {
+        std::fprintf(stderr, "ORBextractor (orbx): a stereo pair must be two CV_8UC1 images of one size\n");
+        std::abort();
+    }
+    EnsureContext(left.cols, left.rows);
+    mnLastWidth = left.cols;
+    mnLastHeight = left.rows;
+    const int cap = EnsureBuffers(left.cols, left.rows, 2);
+    orbx_kp* kps = reinterpret_cast<orbx_kp*>(&mvKpBuf[0]);
+    vuRight.assign((size_t)cap, -1.0f);
+    vDepth.assign((size_t)cap, -1.0f);
+    int n[2] = {0, 0};
+    const int rc = orbx_extract_pair(mpCtx, left.data, (int)left.step, right.data, (int)right.step, left.cols, left.rows, kps, cap,
+                                     &mvDescBuf[0], n, mb, mbf, &vuRight[0], &vDepth[0]);
+    if (rc != ORBX_OK) Fatal("orbx_extract_pair", rc, mpCtx);
+    FillKeyPoints(kps, n[0], keysLeft);
+    FillDescriptors(&mvDescBuf[0], n[0], descLeft);
+    FillKeyPoints(kps + cap, n[1], keysRight);
+    FillDescriptors(&mvDescBuf[0] + (size_t)cap * 32, n[1], descRight);
+    vuRight.resize((size_t)n[0]);
+    vDepth.resize((size_t)n[0]);
 }
 
 // Source compatibility only (reference src/ORBextractor.cc:507-570): splits the node's box at the

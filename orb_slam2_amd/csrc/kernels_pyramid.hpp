@@ -289,6 +289,32 @@ __host__ __device__ __forceinline__ int reflect101(int p, int len) {
     return p >= len ? 2 * len - 2 - p : p;
 }
 
+// The pyramid as ComputePyramid leaves it in mvImagePyramid (reference src/ORBextractor.cc:1227-1245): every level
+// inside a buffer that carries a `border`-pixel BORDER_REFLECT_101 rim (cv::copyMakeBorder), rows w + 2 * border
+// bytes apart, the levels of one frame one after the other at dst + off[level].  The extractor itself never reads the
+// rim; it exists for the callers that read the public member.  Thread = one byte of a padded level.
+// grid = ceil(off[nlevels] / 256), block = 256.
+struct PadDev {
+    const uint8_t* src[ORBX_MAX_LEVELS];
+    int32_t spitch[ORBX_MAX_LEVELS];
+    int32_t w[ORBX_MAX_LEVELS], h[ORBX_MAX_LEVELS];
+    uint32_t off[ORBX_MAX_LEVELS + 1];  // first byte of each padded level; [nlevels] = total
+    uint8_t* dst;
+    int32_t nlevels, border;
+};
+
+__global__ __launch_bounds__(256) void k_pad_levels(PadDev P) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= P.off[P.nlevels]) return;
+    int l = 0;
+    while (l + 1 < P.nlevels && i >= P.off[l + 1]) ++l;
+    const int pw = P.w[l] + 2 * P.border;
+    const uint32_t r = i - P.off[l];
+    const int y = (int)(r / (uint32_t)pw), x = (int)(r - (uint32_t)y * (uint32_t)pw);
+    const int sy = reflect101(y - P.border, P.h[l]), sx = reflect101(x - P.border, P.w[l]);
+    P.dst[i] = P.src[l][(uint64_t)sy * P.spitch[l] + sx];
+}
+
 // cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) on 8UC1, OpenCV 3.4.5 fixed-point path:
 // taps 18,34,49,55,49,34,18 (/256, sum 257); row pass exact (<= 65535); column pass
 // min(255, (sum + 32768) >> 16).

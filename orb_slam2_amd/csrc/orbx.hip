@@ -175,9 +175,21 @@ struct orbx_ctx {
     // launch graph of the single-frame host path (captured once per image size, replayed by orbx_extract)
     hipGraphExec_t graph_exec = nullptr;
     int graph_w = -1, graph_h = -1, graph_cap = 0;
+    int graph_n = 0;             // frames per launch: 1, or 2 (a stereo pair)
+    bool graph_stereo = false;   // the pair's stereo association is part of the graph
+    float graph_mb = 0.f, graph_mbf = 0.f;
+    int graph_pad = 0;           // border of the padded pyramid the graph leaves in h_pad (0: none)
     bool capturing = false;
-    void* h_gin = nullptr;   // pinned: the frame at device pitch (source of the graph's upload node)
-    void* h_gout = nullptr;  // pinned: [cap keypoints][cap descriptors][count] (target of its download nodes)
+    void* h_gin = nullptr;   // pinned: the frames at device pitch (source of the graph's upload node)
+    void* h_gout = nullptr;  // pinned: [n * cap keypoints][n * cap descriptors][4 counts][cap mvuRight][cap mvDepth] (targets of its download nodes)
+    // The pyramid with its reflected border (mvImagePyramid's layout), for single-image calls: built on the device after
+    // the extraction and copied to pinned host memory the caller reads in place (orbx_set_keep_pyramid)
+    int pad_border = 0;
+    DevBuf d_pad;
+    void* h_pad = nullptr;
+    size_t h_pad_bytes = 0;
+    uint32_t pad_off[ORBX_MAX_LEVELS + 1] = {};
+    bool pad_valid = false;
 
     uint8_t* scratch = nullptr;  // this device's copy of the library's static scratch array
     // kStatusWords words in pinned host memory that the kernels can write (see orbx_device.h): a kernel that meets a
@@ -412,6 +424,51 @@ int ensure_stage(orbx_ctx* c, size_t bytes) {
     }
     HIP_TRY(c, hipHostMalloc(&c->h_stage, bytes, hipHostMallocDefault));
     c->h_stage_bytes = bytes;
+    return ORBX_OK;
+}
+
+// Device and pinned host room for the padded pyramid of one frame of the current geometry; fills pad_off.
+int ensure_pad(orbx_ctx* c) {
+    const int b = c->pad_border;
+    size_t total = 0;
+    for (int l = 0; l < c->tab.nlevels; ++l) {
+        c->pad_off[l] = (uint32_t)total;
+        total += align_up((size_t)(c->levels[l].w + 2 * b) * (c->levels[l].h + 2 * b), 64);
+    }
+    c->pad_off[c->tab.nlevels] = (uint32_t)total;
+    int rc = ensure(c, &c->d_pad, total);
+    if (rc) return rc;
+    if (total > c->h_pad_bytes) {
+        { int rc_ = sync_ctx(c); if (rc_) return rc_; }
+        drop_graph(c);
+        if (c->h_pad) HIP_TRY(c, hipHostFree(c->h_pad));
+        c->h_pad = nullptr;
+        c->h_pad_bytes = 0;
+        c->pad_valid = false;
+        HIP_TRY(c, hipHostMalloc(&c->h_pad, total, hipHostMallocDefault));
+        c->h_pad_bytes = total;
+    }
+    return ORBX_OK;
+}
+
+// Enqueues, on the main stream, the padded pyramid of frame 0 of c->B and its copy to c->h_pad (ensure_pad has run).
+int enqueue_pad(orbx_ctx* c) {
+    PadDev P;
+    std::memset(&P, 0, sizeof(P));
+    const BatchDev& B = c->B;
+    for (int l = 0; l < B.nlevels; ++l) {
+        P.src[l] = B.lv[l].img;
+        P.spitch[l] = B.lv[l].pitch;
+        P.w[l] = B.lv[l].w;
+        P.h[l] = B.lv[l].h;
+    }
+    for (int l = 0; l <= B.nlevels; ++l) P.off[l] = c->pad_off[l];
+    P.dst = (uint8_t*)c->d_pad.p;
+    P.nlevels = B.nlevels;
+    P.border = c->pad_border;
+    const uint32_t total = c->pad_off[B.nlevels];
+    hipLaunchKernelGGL(k_pad_levels, dim3((total + 255) / 256), dim3(256), 0, c->stream, P);
+    HIP_TRY(c, hipMemcpyAsync(c->h_pad, c->d_pad.p, total, hipMemcpyDeviceToHost, c->stream));
     return ORBX_OK;
 }
 
@@ -1031,36 +1088,65 @@ int extract_batch_pipelined(orbx_ctx* c, int n, const uint8_t* const* imgs, int 
     return ORBX_OK;
 }
 
-// One frame from host memory as ONE graph launch: upload, the whole launch sequence of run_batch on
-// its three streams, and the download of the results are captured once per image size and replayed
-// per call, so that a small image costs one submission instead of thirteen launches and a dozen
-// event operations.  Everything the graph touches is fixed for the life of the graph: pinned input
-// and output buffers of its own, arena set 0, retained-point set 0, the context's result buffers.
-int build_graph(orbx_ctx* c, int width, int height, int cap) {
+// One frame -- or one stereo pair -- from host memory as ONE graph launch: upload, the whole launch sequence of
+// run_batch on its streams, for a pair the stereo association behind it, and the download of the results are captured
+// once per image size and replayed per call, so that a small image costs one submission instead of thirteen launches
+// and a dozen event operations.  Everything the graph touches is fixed for the life of the graph: pinned input and
+// output buffers of its own, arena set 0, retained-point set 0, the context's result buffers and stereo scratch.
+struct GraphWant {
+    int w, h, cap, n;      // n = 1, or 2: frames 0 and 1 are the left and the right image of a pair
+    bool stereo;           // n == 2: Frame::ComputeStereoMatches on the pair, inside the graph
+    float mb, mbf;
+    int pad;               // n == 1: border of the padded pyramid to leave in h_pad (0: none)
+};
+size_t graph_counts_off(const GraphWant& g) { return (size_t)g.n * g.cap * (sizeof(orbx_kp) + 32); }
+size_t graph_stereo_off(const GraphWant& g) { return graph_counts_off(g) + 16; }
+
+int build_graph(orbx_ctx* c, const GraphWant& g) {
     drop_graph(c);
     int rc = sync_ctx(c);  // no event of an earlier batch may be waited for inside the capture
     if (rc) return rc;
     if ((rc = ensure_aux_streams(c))) return rc;
     const size_t plane = c->plane[0];
-    const size_t out_bytes = (size_t)cap * (sizeof(orbx_kp) + 32) + 4;
-    HIP_TRY(c, hipHostMalloc(&c->h_gin, plane, hipHostMallocDefault));
+    const size_t out_bytes = graph_stereo_off(g) + (g.stereo ? (size_t)g.cap * 8 : 0);
+    // everything that may allocate happens before the capture starts
+    StereoScratch scr = {};
+    if (g.stereo) {
+        if ((rc = ensure(c, &c->d_st_u, (size_t)g.cap * 4))) return rc;
+        if ((rc = ensure(c, &c->d_st_depth, (size_t)g.cap * 4))) return rc;
+        if ((rc = stereo_scratch_ctx(c, 1, g.cap, c->levels[0].h, &scr))) return rc;
+    }
+    if (g.pad && (rc = ensure_pad(c))) return rc;
+    HIP_TRY(c, hipHostMalloc(&c->h_gin, plane * g.n, hipHostMallocDefault));
     HIP_TRY(c, hipHostMalloc(&c->h_gout, out_bytes, hipHostMallocDefault));
-    std::memset(c->h_gin, 0, plane);
+    std::memset(c->h_gin, 0, plane * g.n);
     c->arena_desc[0] = c->arena_desc[1] = -1;
     hipGraph_t graph = nullptr;
     HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     c->capturing = true;
+    orbx_kp* d_kps = (orbx_kp*)c->d_out_kps.p;
+    uint8_t* d_desc = (uint8_t*)c->d_out_desc.p;
+    int32_t* d_cnt = (int32_t*)c->d_out_n.p;
     auto body = [&]() -> int {
-        HIP_TRY(c, hipMemcpyAsync(c->d_pyr[0].p, c->h_gin, plane, hipMemcpyHostToDevice, c->stream));
-        int rc_ = run_batch(c, 1, nullptr, 0, 0, (orbx_kp*)c->d_out_kps.p, cap, (uint8_t*)c->d_out_desc.p,
-                            (int32_t*)c->d_out_n.p, 0, 0, -1, 0, true);
+        HIP_TRY(c, hipMemcpyAsync(c->d_pyr[0].p, c->h_gin, plane * g.n, hipMemcpyHostToDevice, c->stream));
+        int rc_ = run_batch(c, g.n, nullptr, 0, 0, d_kps, g.cap, d_desc, d_cnt, 0, 0, -1, 0, true);
         if (rc_) return rc_;
         if ((rc_ = join(c))) return rc_;  // the descriptor stream rejoins the capturing stream
+        if (g.stereo &&
+            (rc_ = run_stereo(c, c, 1, 0, 1, 0, d_kps, d_kps + g.cap, d_desc, d_desc + (size_t)g.cap * 32, d_cnt, d_cnt + 1, 0, 0,
+                              g.cap, g.mb, g.mbf, (float*)c->d_st_u.p, (float*)c->d_st_depth.p, scr)))
+            return rc_;
+        if (g.pad && (rc_ = enqueue_pad(c))) return rc_;
         uint8_t* o = (uint8_t*)c->h_gout;
-        HIP_TRY(c, hipMemcpyAsync(o, c->d_out_kps.p, (size_t)cap * sizeof(orbx_kp), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(o + (size_t)cap * sizeof(orbx_kp), c->d_out_desc.p, (size_t)cap * 32, hipMemcpyDeviceToHost,
-                                  c->stream));
-        HIP_TRY(c, hipMemcpyAsync(o + (size_t)cap * (sizeof(orbx_kp) + 32), c->d_out_n.p, 4, hipMemcpyDeviceToHost, c->stream));
+        const size_t nk = (size_t)g.n * g.cap;
+        HIP_TRY(c, hipMemcpyAsync(o, d_kps, nk * sizeof(orbx_kp), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(o + nk * sizeof(orbx_kp), d_desc, nk * 32, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(o + graph_counts_off(g), d_cnt, (size_t)g.n * 4, hipMemcpyDeviceToHost, c->stream));
+        if (g.stereo) {
+            HIP_TRY(c, hipMemcpyAsync(o + graph_stereo_off(g), c->d_st_u.p, (size_t)g.cap * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(o + graph_stereo_off(g) + (size_t)g.cap * 4, c->d_st_depth.p, (size_t)g.cap * 4,
+                                      hipMemcpyDeviceToHost, c->stream));
+        }
         return ORBX_OK;
     };
     rc = body();
@@ -1087,43 +1173,61 @@ int build_graph(orbx_ctx* c, int width, int height, int cap) {
         drop_graph(c);
         return rc;
     }
-    c->graph_w = width;
-    c->graph_h = height;
-    c->graph_cap = cap;
+    c->graph_w = g.w;
+    c->graph_h = g.h;
+    c->graph_cap = g.cap;
+    c->graph_n = g.n;
+    c->graph_stereo = g.stereo;
+    c->graph_mb = g.mb;
+    c->graph_mbf = g.mbf;
+    c->graph_pad = g.pad;
     return ORBX_OK;
 }
 
-int extract_graph(orbx_ctx* c, const uint8_t* img, int width, int height, int stride, orbx_kp* kps, int kp_cap,
-                  uint8_t* desc, int* n_out, int cap) {
+// imgs / strides: g.n host images.  kps[g.n * kp_cap], desc[g.n * kp_cap * 32], n_out[g.n]; u_right / depth [kp_cap] when g.stereo.
+int extract_graph(orbx_ctx* c, const GraphWant& g, const uint8_t* const* imgs, const int* strides, orbx_kp* kps, int kp_cap,
+                  uint8_t* desc, int* n_out, float* u_right, float* depth) {
     int rc;
-    if (!c->graph_exec || c->graph_w != width || c->graph_h != height || c->graph_cap != cap) {
-        if ((rc = build_graph(c, width, height, cap))) return rc;
+    if (!c->graph_exec || c->graph_w != g.w || c->graph_h != g.h || c->graph_cap != g.cap || c->graph_n != g.n ||
+        c->graph_stereo != g.stereo || c->graph_pad != g.pad || (g.stereo && (c->graph_mb != g.mb || c->graph_mbf != g.mbf))) {
+        if ((rc = build_graph(c, g))) return rc;
     } else if ((rc = sync_ctx(c))) {  // an earlier asynchronous batch may still use arena set 0
         return rc;
     }
     const int pitch = c->pitch[0];
-    for (int y = 0; y < height; ++y) std::memcpy((uint8_t*)c->h_gin + (size_t)y * pitch, img + (size_t)y * stride, (size_t)width);
+    const size_t plane = c->plane[0];
+    for (int i = 0; i < g.n; ++i)
+        for (int y = 0; y < g.h; ++y)
+            std::memcpy((uint8_t*)c->h_gin + i * plane + (size_t)y * pitch, imgs[i] + (size_t)y * strides[i], (size_t)g.w);
+    c->pad_valid = false;
     HIP_TRY(c, hipGraphLaunch(c->graph_exec, c->stream));
     // the host-side view of the batch the graph computes (read-backs and the stereo stage use it)
-    fill_batch(c, 1, nullptr, 0, 0, 1, 0, 0);
+    fill_batch(c, g.n, nullptr, 0, 0, g.n, 0, 0);
     c->arena_set = 0;
     c->kp_set = 0;
     c->last_kps = (orbx_kp*)c->d_out_kps.p;
     c->last_desc = (uint8_t*)c->d_out_desc.p;
     c->last_n = (int32_t*)c->d_out_n.p;
-    c->last_kp_cap = cap;
+    c->last_kp_cap = g.cap;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->have_last = true;
     c->last_chunked = false;
     { int rc_ = check_status(c); if (rc_) return rc_; }
+    c->pad_valid = g.pad != 0;
     const uint8_t* o = (const uint8_t*)c->h_gout;
-    int32_t k = 0;
-    std::memcpy(&k, o + (size_t)cap * (sizeof(orbx_kp) + 32), 4);
-    k = std::max(0, std::min(k, std::min(cap, kp_cap)));
-    *n_out = k;
-    if (k > 0) {
-        std::memcpy(kps, o, (size_t)k * sizeof(orbx_kp));
-        std::memcpy(desc, o + (size_t)cap * sizeof(orbx_kp), (size_t)k * 32);
+    for (int i = 0; i < g.n; ++i) {
+        int32_t k = 0;
+        std::memcpy(&k, o + graph_counts_off(g) + 4 * i, 4);
+        k = std::max(0, std::min(k, std::min(g.cap, kp_cap)));
+        n_out[i] = k;
+        if (k > 0) {
+            std::memcpy(kps + (size_t)i * kp_cap, o + (size_t)i * g.cap * sizeof(orbx_kp), (size_t)k * sizeof(orbx_kp));
+            std::memcpy(desc + (size_t)i * kp_cap * 32, o + (size_t)g.n * g.cap * sizeof(orbx_kp) + (size_t)i * g.cap * 32, (size_t)k * 32);
+        }
+    }
+    if (g.stereo && n_out[0] > 0) {
+        std::memcpy(u_right, o + graph_stereo_off(g), (size_t)n_out[0] * 4);
+        std::memcpy(depth, o + graph_stereo_off(g) + (size_t)g.cap * 4, (size_t)n_out[0] * 4);
     }
     return ORBX_OK;
 }
@@ -1234,6 +1338,8 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
     for (DevBuf* b : bufs) release(b);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_status) (void)hipHostFree(c->h_status);
+    if (c->h_pad) (void)hipHostFree(c->h_pad);
+    release(&c->d_pad);
     for (int i = 0; i < kPipeSlots; ++i) {
         if (c->h_up[i]) (void)hipHostFree(c->h_up[i]);
         if (c->h_res[i]) (void)hipHostFree(c->h_res[i]);
@@ -1310,8 +1416,12 @@ extern "C" int orbx_extract_batch(orbx_ctx* c, int n, const uint8_t* const* imgs
     if ((rc = ensure(c, &c->d_out_kps, (size_t)n * cap * sizeof(orbx_kp)))) return rc;
     if ((rc = ensure(c, &c->d_out_desc, (size_t)n * cap * 32))) return rc;
     if ((rc = ensure(c, &c->d_out_n, (size_t)n * 4))) return rc;
-    if (n == 1 && !c->dbg_no_graph && !c->dbg_no_overlap && !c->profiling)
-        return extract_graph(c, imgs[0], width, height, strides[0], kps, kp_cap, desc, n_out, cap);
+    if (n == 1 && !c->dbg_no_graph && !c->dbg_no_overlap && !c->profiling) {
+        const GraphWant g = {width, height, cap, 1, false, 0.f, 0.f, c->pad_border};
+        return extract_graph(c, g, imgs, strides, kps, kp_cap, desc, n_out, nullptr, nullptr);
+    }
+    c->pad_valid = false;
+    if (n == 1 && c->pad_border && (rc = ensure_pad(c))) return rc;
     if (n >= kPipeMinFrames) {
         rc = extract_batch_pipelined(c, n, imgs, width, height, strides, kps, kp_cap, desc, n_out, cap);
         if (trace) std::fprintf(stderr, "orbx_extract_batch (pipelined) host ms: %.3f\n", now() - t_a);
@@ -1324,6 +1434,9 @@ extern "C" int orbx_extract_batch(orbx_ctx* c, int n, const uint8_t* const* imgs
                    (int32_t*)c->d_out_n.p, aset, kset);
     if (rc) return rc;
     if ((rc = join(c))) return rc;
+    if (n == 1 && c->pad_border) {  // the padded pyramid of a single image (plain launches: the graph has its own copy of this)
+        if ((rc = enqueue_pad(c))) return rc;
+    }
     const double t_c = now();
     std::vector<int32_t> cnt(n);
     HIP_TRY(c, hipMemcpyAsync(cnt.data(), c->d_out_n.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1340,6 +1453,7 @@ extern "C" int orbx_extract_batch(orbx_ctx* c, int n, const uint8_t* const* imgs
         }
     }
     { int rc_ = sync_ctx(c); if (rc_) return rc_; }
+    c->pad_valid = n == 1 && c->pad_border != 0;  // copied before the synchronisation above returned
     if (trace)
         std::fprintf(stderr, "orbx_extract_batch host ms: upload-enqueue %.3f launch %.3f wait+counts %.3f download %.3f\n",
                      t_b - t_a, t_c - t_b, t_d - t_c, now() - t_d);
@@ -1351,6 +1465,60 @@ extern "C" int orbx_extract(orbx_ctx* c, const uint8_t* img, int width, int heig
     const uint8_t* imgs[1] = {img};
     int strides[1] = {stride};
     return orbx_extract_batch(c, 1, imgs, width, height, strides, kps, kp_cap, desc, n_out);
+}
+
+extern "C" int orbx_extract_pair(orbx_ctx* c, const uint8_t* left, int stride_left, const uint8_t* right, int stride_right,
+                                 int width, int height, orbx_kp* kps, int kp_cap, uint8_t* desc, int n_out[2], float mb,
+                                 float mbf, float* u_right, float* depth) {
+    if (!left || !right || !kps || !desc || !n_out || stride_left < width || stride_right < width) return ORBX_E_INVALID;
+    const bool stereo = u_right != nullptr || depth != nullptr;
+    if (stereo && (!u_right || !depth || !(mb > 0.0f) || !(mbf > 0.0f))) return ORBX_E_INVALID;
+    int rc = check_call(c, 2, width, height, kp_cap);
+    if (rc) return rc;
+    if ((rc = ensure_arenas(c, 2, true))) return rc;
+    const int cap = max_keypoints(c->levels);
+    if (cap > 65535) return ORBX_E_CAPACITY;  // the stereo stage's limit
+    if ((rc = ensure(c, &c->d_out_kps, (size_t)2 * cap * sizeof(orbx_kp)))) return rc;
+    if ((rc = ensure(c, &c->d_out_desc, (size_t)2 * cap * 32))) return rc;
+    if ((rc = ensure(c, &c->d_out_n, (size_t)2 * 4))) return rc;
+    const uint8_t* imgs[2] = {left, right};
+    const int strides[2] = {stride_left, stride_right};
+    if (!c->dbg_no_graph && !c->dbg_no_overlap && !c->profiling) {
+        const GraphWant g = {width, height, cap, 2, stereo, mb, mbf, 0};
+        return extract_graph(c, g, imgs, strides, kps, kp_cap, desc, n_out, u_right, depth);
+    }
+    // plain launches (diagnostic switches): the batch entry point, then the stereo stage of the one pair
+    if ((rc = orbx_extract_batch(c, 2, imgs, width, height, strides, kps, kp_cap, desc, n_out))) return rc;
+    if (stereo) {
+        int nl = 0;
+        std::vector<float> u(cap), d(cap);
+        if ((rc = orbx_stereo_match(c, 0, c, 1, mb, mbf, u.data(), d.data(), cap, &nl))) return rc;
+        const int k = std::min(nl, n_out[0]);
+        std::memcpy(u_right, u.data(), (size_t)k * 4);
+        std::memcpy(depth, d.data(), (size_t)k * 4);
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_set_keep_pyramid(orbx_ctx* c, int border) {
+    if (!c || border < 0 || border > 64) return ORBX_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->prm.device_id));
+    { int rc_ = sync_ctx(c); if (rc_) return rc_; }
+    if (border != c->pad_border) drop_graph(c);  // the captured launch sequence includes the padded pyramid or not
+    c->pad_border = border;
+    c->pad_valid = false;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_padded_level(orbx_ctx* c, int level, const uint8_t** base, int* width, int* height, int* stride) {
+    if (!c || !base) return ORBX_E_INVALID;
+    if (!c->pad_valid || !c->have_last) return ORBX_E_STATE;
+    if (level < 0 || level >= c->B.nlevels) return ORBX_E_INVALID;
+    *base = (const uint8_t*)c->h_pad + c->pad_off[level];
+    if (width) *width = c->B.lv[level].w;
+    if (height) *height = c->B.lv[level].h;
+    if (stride) *stride = c->B.lv[level].w + 2 * c->pad_border;
+    return ORBX_OK;
 }
 
 extern "C" int orbx_stereo_match_batch_device(orbx_ctx* c, int n_pairs, const orbx_kp* d_kps, int kp_cap,

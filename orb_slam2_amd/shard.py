@@ -22,10 +22,10 @@ def pair_shard(n_pairs, rank, world):
 
 
 def frame_shard(n_frames, rank, world):
-    """[first, last) frame indices of `rank` for an even number of frames (pairs kept together)."""
-    assert n_frames % 2 == 0
-    a, b = pair_shard(n_frames // 2, rank, world)
-    return 2 * a, 2 * b
+    """[first, last) frame indices of `rank` (pairs kept together); the same cut as the library's
+    orbx_host_frame_shard, which the in-process worker pool uses."""
+    a, b = pair_shard((n_frames + 1) // 2, rank, world)
+    return min(2 * a, n_frames), min(2 * b, n_frames)
 
 
 def max_over_ranks(value, dist=None, device=None):

@@ -33,6 +33,7 @@ struct Rect {
 struct Size {
     int width, height;
     Size(int w, int h) : width(w), height(h) {}
+    bool operator!=(const Size& o) const { return width != o.width || height != o.height; }
 };
 
 class KeyPoint {
@@ -64,6 +65,8 @@ public:
     }
     bool empty() const { return data == 0 || rows == 0 || cols == 0; }
     int type() const { return CV_8UC1; }
+    bool isContinuous() const { return step == (size_t)cols || rows <= 1; }
+    Size size() const { return Size(cols, rows); }
     uchar* ptr(int i = 0) { return data + (size_t)i * step; }
     const uchar* ptr(int i = 0) const { return data + (size_t)i * step; }
     Mat operator()(const Rect& r) const {

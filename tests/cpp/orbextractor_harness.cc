@@ -7,10 +7,13 @@
 //       frames.raw: 2*pairs frames (left, right, left, ...).  Two extractor instances live for the whole
 //       run; per pair each one is called from a thread of its own that is created for the call and
 //       joined after it (threaded = 1; the calling thread does both calls when 0), then the left
-//       instance matches against the right.  out.bin per pair: int32 Kl, Kl*28 + Kl*32 bytes, int32 Kr,
+//       instance matches against the right; threaded = 2: ONE instance, ExtractStereoPair per pair.
+//       Prints the median time of a pair (extractions + association, no file output) on stdout.  out.bin per pair: int32 Kl, Kl*28 + Kl*32 bytes, int32 Kr,
 //       Kr*28 + Kr*32 bytes, int32 N, N floats mvuRight, N floats mvDepth.
 // extract's out.bin: int32 K, K*28 bytes keypoints (cv::KeyPoint field order), K*32 bytes descriptors,
 // then per level: int32 w, int32 h, (w+38)*(h+38) bytes of the padded pyramid buffer.
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -122,7 +125,10 @@ int main(int argc, char** argv) {
         const int nf = std::atoi(argv[2]), nl = std::atoi(argv[4]);
         const float sc = (float)std::atof(argv[3]);
         const int w = std::atoi(argv[5]), h = std::atoi(argv[6]), pairs = std::atoi(argv[7]);
-        const bool threaded = std::atoi(argv[12]) != 0;
+        const int mode = std::atoi(argv[12]);
+        const bool threaded = mode == 1;
+        const float mb = (float)std::atof(argv[9]), mbf = (float)std::atof(argv[10]);
+        std::vector<double> ms;
         std::vector<unsigned char> raw((size_t)w * h * 2 * pairs);
         FILE* f = std::fopen(argv[8], "rb");
         if (!f || std::fread(&raw[0], 1, raw.size(), f) != raw.size()) return 2;
@@ -135,7 +141,11 @@ int main(int argc, char** argv) {
             cv::Mat iml(h, w, CV_8UC1, &raw[(size_t)(2 * p) * w * h], (size_t)w);
             cv::Mat imr(h, w, CV_8UC1, &raw[(size_t)(2 * p + 1) * w * h], (size_t)w);
             Extraction el, er;
-            if (threaded) {
+            std::vector<float> u, d;
+            const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+            if (mode == 2) {
+                left.ExtractStereoPair(iml, imr, el.kps, el.desc, er.kps, er.desc, mb, mbf, u, d);
+            } else if (threaded) {
                 // Frame::Frame (stereo), reference src/Frame.cc:78-81: two threads per frame, joined
                 std::thread tl(ExtractORB, &left, &iml, &el);
                 std::thread tr(ExtractORB, &right, &imr, &er);
@@ -145,8 +155,8 @@ int main(int argc, char** argv) {
                 ExtractORB(&left, &iml, &el);
                 ExtractORB(&right, &imr, &er);
             }
-            std::vector<float> u, d;
-            left.ComputeStereoMatches(right, (float)std::atof(argv[9]), (float)std::atof(argv[10]), u, d);
+            if (mode != 2) left.ComputeStereoMatches(right, mb, mbf, u, d);
+            ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
             if (u.size() != el.kps.size() || d.size() != el.kps.size()) return 5;
             WriteExtraction(o, el);
             WriteExtraction(o, er);
@@ -158,6 +168,10 @@ int main(int argc, char** argv) {
             }
         }
         std::fclose(o);
+        if (ms.size() > 4) ms.erase(ms.begin(), ms.begin() + 2);  // the first calls create contexts and capture graphs
+        std::sort(ms.begin(), ms.end());
+        std::printf("pair_ms median %.4f p10 %.4f p90 %.4f pairs %d mode %d\n", ms[ms.size() / 2], ms[ms.size() / 10],
+                    ms[ms.size() * 9 / 10], (int)ms.size(), mode);
         return 0;
     }
     std::fprintf(stderr, "usage: see source\n");

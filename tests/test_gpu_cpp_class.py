@@ -104,12 +104,13 @@ def test_cpp_two_threads_two_instances(oracle, tmp_path):
     frames.tofile(raw)
     mb, mbf = 0.11, 47.9
     blobs = []
-    for threaded in (1, 0):
+    for threaded in (1, 0, 2):   # 2: one instance, ExtractStereoPair (one graph launch per pair)
         out = tmp_path / ("out%d.bin" % threaded)
         subprocess.check_call([EXE, "threads", str(nf), "1.2", str(nl), str(w), str(h), str(pairs), str(raw), repr(mb),
                                repr(mbf), str(out), str(threaded)], timeout=300)
         blobs.append(out.read_bytes())
     assert blobs[0] == blobs[1], "two threads and one thread disagree"
+    assert blobs[0] == blobs[2], "two instances and ExtractStereoPair on one instance disagree"
     blob, off = blobs[0], 0
     ol, orr = oracle.Oracle(nf, 1.2, nl, 20, 7), oracle.Oracle(nf, 1.2, nl, 20, 7)
     matched = 0

@@ -4,6 +4,8 @@ Integer stages (pyramid, blur, FAST candidates, quadtree retention, descriptors)
 bit-exact; float outputs (angle, scaled coordinates) are produced by the same IEEE operation
 sequence on both sides and are compared bit-exactly too (tolerance 0).
 """
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -476,6 +478,63 @@ def test_single_frame_launch_graph_and_plain_launches(oracle):
     ex.close()
     for a in (d_in, d_kps, d_desc, d_n):
         a.free()
+
+
+def test_extract_pair_one_graph(oracle):
+    """orbx_extract_pair: both images of a pair and the stereo association as one call on one context, against the
+    oracle; a change of mb / mbf re-captures; plain launches (the no-graph switch) give the same."""
+    w, h, nf, nl = 1241, 376, 2000, 8
+    ex = oa.ORBextractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=2, keep_pyramid=False)
+    ol, orr = oracle.Oracle(nf, 1.2, nl, 20, 7), oracle.Oracle(nf, 1.2, nl, 20, 7)
+    for i, (mb, mbf, plain) in enumerate(((0.5371657, 386.1448, 0), (0.5371657, 386.1448, 0), (0.3, 200.0, 0),
+                                          (0.5371657, 386.1448, 1))):
+        wide = synth.make_frame(w + 32, h, 3, 60 + i)
+        left = np.ascontiguousarray(wide[:, :w])
+        right = np.ascontiguousarray(np.clip(wide[:, 7:w + 7].astype(np.int32) +
+                                             np.random.default_rng(i).integers(-2, 3, (h, w)), 0, 255).astype(np.uint8))
+        ex.set_debug_flag(oa.FLAG_NO_GRAPH, plain)
+        (kl, dl), (kr, dr), u, d = ex.extract_pair(left, right, mb, mbf)
+        okl, odl = ol.extract(left)
+        okr, odr = orr.extract(right)
+        _check_final(kl, dl, okl, odl)
+        _check_final(kr, dr, okr, odr)
+        ou, od, _, kept = oracle.stereo_match(ol, orr, np.float32(mb), np.float32(mbf))
+        assert kept > 200
+        assert (u.view(np.uint32) == ou.view(np.uint32)).all() and (d.view(np.uint32) == od.view(np.uint32)).all()
+        # the pyramids of both images are there for read-backs
+        assert (ex.pyramid_level(1, 3) == orr.level(3)).all() and (ex.pyramid_level(0, 7) == ol.level(7)).all()
+    # without the association
+    (kl, dl), (kr, dr), u, d = ex.extract_pair(left, right)
+    assert u is None and d is None
+    _check_final(kl, dl, okl, odl)
+    _check_final(kr, dr, okr, odr)
+    ex.close()
+    one = oa.ORBextractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=1, keep_pyramid=False)
+    with pytest.raises(oa.OrbxError, match="capacity"):
+        one.extract_pair(left, right)
+    one.close()
+
+
+def test_padded_pyramid_built_on_the_device(oracle):
+    """mvImagePyramid's layout (19-px reflect-101 rim around every level) comes out of the extraction's own submission,
+    in the graph path and with plain launches, and follows a change of image size."""
+    ex = oa.ORBextractor(1000, 1.2, 8, 20, 7, max_width=752, max_height=480, max_batch=1, keep_pyramid=True)
+    orc = oracle.Oracle(1000, 1.2, 8, 20, 7)
+    for (w, h, idx, plain) in ((640, 480, 1, 0), (640, 480, 2, 0), (752, 480, 3, 0), (400, 300, 4, 1), (640, 480, 5, 1)):
+        ex.set_debug_flag(oa.FLAG_NO_GRAPH, plain)
+        img = synth.make_frame(w, h, 1, idx)
+        kps, desc = ex(img)
+        okps, odesc = orc.extract(img)
+        _check_final(kps, desc, okps, odesc)
+        for l in range(8):
+            view = ex.padded_level(l, copy=False)
+            lw, lh = orc.level_dims(l)
+            assert view.shape == (lh, lw) and view.strides[0] == lw + 38
+            base = np.frombuffer((ctypes.c_uint8 * ((lw + 38) * (lh + 38))).from_address(view.ctypes.data - 19 * (lw + 38) - 19),
+                                 np.uint8).reshape(lh + 38, lw + 38)
+            assert (base == orc.padded_level(l)).all(), "padded level %d of %dx%d" % (l, w, h)
+            assert (ex.mvImagePyramid[l] == orc.level(l)).all()
+    ex.close()
 
 
 def test_errors():

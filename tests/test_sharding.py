@@ -62,3 +62,26 @@ def test_two_rank_gloo_job(oracle):
     orc = oracle.Oracle(300, 1.2, 4, 20, 7)
     expect = sum(len(orc.extract(synth.make_frame(200, 160, 9, i))[0]) for i in range(n_frames))
     assert s == float(expect) and expect > 0
+
+
+def test_library_frame_shard_equals_the_python_cut():
+    """orbx_host_frame_shard (what the in-process worker pool cuts a stream with) against shard.frame_shard: a
+    partition into contiguous runs, pairs never split, sizes within one pair of each other."""
+    import orb_slam2_amd as oa
+    for n in (0, 1, 2, 3, 7, 8, 64, 511, 512, 8192):
+        for world in (1, 2, 3, 4, 8, 16):
+            spans = [oa.host_frame_shard(n, r, world) for r in range(world)]
+            assert spans == [shard.frame_shard(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            for a, b in spans:
+                assert (a % 2 == 0 or a == n) and (b % 2 == 0 or b == n)
+            pairs = [(b - a + 1) // 2 for a, b in spans]       # an odd stream ends in half a pair
+            assert max(pairs) - min(pairs) <= 1
+    L = oa.load_library()
+    import ctypes as C
+    a, b = C.c_int(), C.c_int()
+    assert L.orbx_host_frame_shard(8, 2, 2, C.byref(a), C.byref(b)) == -1
+    assert L.orbx_host_frame_shard(8, 0, 0, C.byref(a), C.byref(b)) == -1
+    assert L.orbx_host_frame_shard(-1, 0, 1, C.byref(a), C.byref(b)) == -1

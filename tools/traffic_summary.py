@@ -40,7 +40,7 @@ def main():
     wr = per_launch(d + "/wr/pmc_counter_collection.csv")
     # one k_octree launch per extraction step: its launch count is the number of steps sampled
     steps = rd["orbx::k_octree"][1]
-    res = {"_note": "bytes per extraction step (512 frames) summed over a kernel's launches of that step, averaged over "
+    res = {"_note": "bytes per extraction step of the profiled command (512 frames for the default configuration) summed over a kernel's launches of that step, averaged over "
                     "the %d steps of `bench.py --steps 2 --warmup 1`; fetch = 2 * FETCH_SIZE KiB (gfx950 correction, "
                     "calibrated), write = WRITE_SIZE KiB" % steps}
     for k in sorted(rd):

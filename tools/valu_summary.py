@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Wave-instruction counts per extraction step of each orbx kernel, from the SQ counter passes of
-tools/pmc_multi.sh (SQ_INSTS_VALU / SALU / LDS / VMEM_RD / VMEM_WR).  A kernel's counts are summed
+tools/pmc_multi.sh (SQ_INSTS_VALU / SALU / LDS / VMEM_RD / VMEM_WR, and the LDS array's cycles: SQ_LDS_IDX_ACTIVE with
+the share SQ_LDS_BANK_CONFLICT of them spent on bank conflicts).  A kernel's counts are summed
 over its launches and divided by the number of steps sampled (= launches of k_octree, one per step).
 
 usage: valu_summary.py <out.json> <pmc_counter_collection.csv> [more csv ...]
@@ -16,7 +17,8 @@ from collections import defaultdict
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from orb_slam2_amd import source_hash  # noqa: E402
 
-WANT = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_WAVES")
+WANT = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_WAVES",
+        "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE")
 
 
 def main():
@@ -35,7 +37,8 @@ def main():
         steps = len(ids.get("k_octree", ())) or 1
         for (name, ctr), v in acc.items():
             res[name][ctr] = v / steps
-    res["_note"] = ("wave instructions per extraction step (512 frames) of `bench.py --steps 2 --warmup 1`, summed over a "
+    res["_note"] = ("wave instructions (and LDS array cycles, in units of 4 clocks) per extraction step of the profiled "
+                    "`bench.py --steps 2 --warmup 1` command (512 frames for the default configuration), summed over a "
                     "kernel's launches of the step; one rocprofv3 --pmc pass per counter group")
     res["_source_sha256"] = source_hash()
     with open(out, "w") as f:
