@@ -489,8 +489,14 @@ def host_to_host(oa, run):
     strides = (C.c_int * n)(*[f.strides[0] for f in frames])
     args = (ex._ctx, n, ptrs, cfg["w"], cfg["h"], strides, kps.ctypes.data_as(C.c_void_p), cap,
             desc.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p))
-    for _ in range(2):      # pinned slots, host threads and the result arrays' pages exist after these
+    # The first calls of a process are not the steady state: the pinned slots are allocated in the first one, and in each
+    # of the first three one hipMemcpyAsync of the download stream blocks the calling thread for about 6 ms inside the
+    # runtime (profiles/r03_h2h_trace_*.txt).  They are timed, reported as first_calls_ms, and kept out of the median.
+    first = []
+    for _ in range(4):
+        t0 = time.perf_counter()
         assert ex._L.orbx_extract_batch(*args) == 0
+        first.append(time.perf_counter() - t0)
     t = []
     for _ in range(11):
         t0 = time.perf_counter()
@@ -500,7 +506,8 @@ def host_to_host(oa, run):
     e = rate_entry(oa, cfg, n, med, cnt, "orbx_extract_batch: %d KITTI-shape frames from pageable host memory, keypoints and "
                                          "descriptors back to host memory (PCIe both ways, chunked and overlapped)" % n)
     e["GBs_in"] = n * cfg["w"] * cfg["h"] / med / 1e9
-    e["spread_ms"] = {"min": 1e3 * min(t), "max": 1e3 * max(t), "calls": len(t)}
+    e["spread_ms"] = {"min": 1e3 * min(t), "max": 1e3 * max(t), "calls": len(t), "max_over_median": max(t) / med,
+                      "calls_ms": [round(1e3 * v, 3) for v in t], "first_calls_ms": [round(1e3 * v, 3) for v in first]}
     return e
 
 

@@ -422,14 +422,23 @@ __device__ __forceinline__ void blur_stream(const __amdgpu_buffer_rsrc_t rs, con
             const int vo = INNER ? (int)(vbase + (uint32_t)((r + PF) * spitch)) : reflect101(min(y0 + r + PF - 3, h + 2), h) * spitch + vcol;
             qC[r % PF] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0, 0);
         }
+        uint32_t wr[4];
+#ifdef ORBX_BLUR_ALIGNED_DOT4
+        // the seven taps of pixel k against the three dwords as they are, with the weights shifted instead of the
+        // pixels: ten v_dot4_u32_u8 and no v_alignbyte_b32 (eight and six the other way)
+        wr[0] = __builtin_amdgcn_udot4(C, 0x12223137u, __builtin_amdgcn_udot4(Lw, 0x31221200u, 0u, false), false);
+        wr[1] = __builtin_amdgcn_udot4(R, 0x00000012u, __builtin_amdgcn_udot4(C, 0x22313731u, __builtin_amdgcn_udot4(Lw, 0x22120000u, 0u, false), false), false);
+        wr[2] = __builtin_amdgcn_udot4(R, 0x00001222u, __builtin_amdgcn_udot4(C, 0x31373122u, __builtin_amdgcn_udot4(Lw, 0x12000000u, 0u, false), false), false);
+        wr[3] = __builtin_amdgcn_udot4(R, 0x00122231u, __builtin_amdgcn_udot4(C, 0x37312212u, 0u, false), false);
+#else
         const uint32_t a0 = __builtin_amdgcn_alignbyte(C, Lw, 1), b0 = __builtin_amdgcn_alignbyte(R, C, 1);
         const uint32_t a1 = __builtin_amdgcn_alignbyte(C, Lw, 2), b1 = __builtin_amdgcn_alignbyte(R, C, 2);
         const uint32_t a2 = __builtin_amdgcn_alignbyte(C, Lw, 3), b2 = __builtin_amdgcn_alignbyte(R, C, 3);
-        uint32_t wr[4];
         wr[0] = __builtin_amdgcn_udot4(b0, 0x00122231u, __builtin_amdgcn_udot4(a0, 0x37312212u, 0u, false), false);
         wr[1] = __builtin_amdgcn_udot4(b1, 0x00122231u, __builtin_amdgcn_udot4(a1, 0x37312212u, 0u, false), false);
         wr[2] = __builtin_amdgcn_udot4(b2, 0x00122231u, __builtin_amdgcn_udot4(a2, 0x37312212u, 0u, false), false);
         wr[3] = __builtin_amdgcn_udot4(R, 0x00122231u, __builtin_amdgcn_udot4(C, 0x37312212u, 0u, false), false);
+#endif
         if (r >= 6) {
             const int y = y0 + r - 6;
             const uint32_t o = blur_pack(blur_col(pr, wr[0], r, 0), blur_col(pr, wr[1], r, 1), blur_col(pr, wr[2], r, 2),

@@ -939,6 +939,26 @@ int ensure_pipeline(orbx_ctx* c, size_t up_bytes, size_t res_bytes) {
     return ORBX_OK;
 }
 
+// The runtime sets up its copy engines lazily: the first asynchronous copies in each direction that find an engine
+// busy each block the calling thread for several milliseconds inside hipMemcpyAsync while another engine's queue
+// is created (seen as one 5-6 ms stall in each of the first three or four batches of a process).  Copies of the
+// pipeline's own shape -- both directions at once, several in flight per stream -- issued once when the pipeline is
+// built move that set-up out of the first batches.
+int warm_pipeline(orbx_ctx* c, size_t up_bytes, size_t res_bytes) {
+    up_bytes = std::min(up_bytes, c->d_pyr[0].bytes);
+    res_bytes = std::min(res_bytes, c->d_out_kps.bytes);
+    for (int round = 0; round < 4; ++round)
+        for (int i = 0; i < kPipeSlots; ++i) {
+            HIP_TRY(c, hipMemcpyAsync(c->d_pyr[0].p, c->h_up[i], up_bytes, hipMemcpyHostToDevice, c->st_up));
+            HIP_TRY(c, hipMemcpyAsync(c->h_res[i], c->d_out_kps.p, res_bytes / 2, hipMemcpyDeviceToHost, c->st_down));
+            HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->h_res[i] + res_bytes / 2, c->d_out_kps.p, res_bytes / 2, hipMemcpyDeviceToHost, c->st_down));
+            HIP_TRY(c, hipMemcpyAsync(c->h_res[i], c->d_out_n.p, 16, hipMemcpyDeviceToHost, c->st_down));
+        }
+    HIP_TRY(c, hipStreamSynchronize(c->st_up));
+    HIP_TRY(c, hipStreamSynchronize(c->st_down));
+    return ORBX_OK;
+}
+
 // A counter one thread advances and others wait on; fail() releases every waiter.
 struct Gate {
     std::mutex m;
@@ -972,9 +992,15 @@ int extract_batch_pipelined(orbx_ctx* c, int n, const uint8_t* const* imgs, int 
     int m = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, kPipeChunkBytes / plane));
     if (c->dbg_pipe_chunk > 0) m = std::max(1, std::min(n, c->dbg_pipe_chunk));  // frames per chunk (tests)
     const size_t res_kps = (size_t)m * cap * sizeof(orbx_kp), res_desc = (size_t)m * cap * 32, res_cnt = (size_t)m * 4;
+    const bool fresh = !c->pipe_made || (size_t)m * plane > c->h_up_bytes || res_kps + res_desc + res_cnt > c->h_res_bytes;
     int rc = ensure_pipeline(c, (size_t)m * plane, res_kps + res_desc + res_cnt);
     if (rc) return rc;
     if ((rc = sync_ctx(c))) return rc;  // nothing of an earlier call is still in flight
+#ifndef ORBX_DIAG_NO_PIPE_WARM  // diagnostic build: the first batches then show the runtime's stalls (kept trace under profiles/)
+    if (fresh && (rc = warm_pipeline(c, (size_t)m * plane, res_kps + res_desc + res_cnt))) return rc;
+#else
+    (void)fresh;
+#endif
     const int aset = c->arena_set ^ 1;
     const int hw = (int)std::max(2u, std::min(12u, std::thread::hardware_concurrency()));
     const int stage_threads = std::max(1, hw * 2 / 3), deliver_threads = std::max(1, hw - stage_threads);
@@ -1046,17 +1072,21 @@ int extract_batch_pipelined(orbx_ctx* c, int n, const uint8_t* const* imgs, int 
         for (int k = 0; k < nchunks; ++k) {
             const int slot = k % kPipeSlots, f0 = first[k], mk = first[k + 1] - f0;
             if (!staged.wait_for(k)) return ORBX_OK;  // the failing thread left its code in worker_rc
+            const double te0 = ptrace ? tnow() : 0.0;
             HIP_TRY(c, hipMemcpyAsync((uint8_t*)c->d_pyr[aset].p + (size_t)f0 * plane, c->h_up[slot], (size_t)mk * plane,
                                       hipMemcpyHostToDevice, c->st_up));
             HIP_TRY(c, hipEventRecord(c->ev_up[slot], c->st_up));
             uploaded.set(k);
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_up[slot], 0));
+            const double te1 = ptrace ? tnow() : 0.0;
             // every chunk works in the same arena set (different frames of it) and alternates the retained-point set
             int rc_ = run_batch(c, mk, nullptr, 0, 0, d_kps + (size_t)f0 * cap, cap, d_desc + (size_t)f0 * cap * 32, d_cnt + f0, aset,
                                 k & 1, n, f0, true);
             if (rc_) return rc_;
             HIP_TRY(c, hipEventRecord(c->ev_done[slot], c->desc_pending[k & 1] ? c->st_desc : c->stream));  // after the descriptors
+            const double te2 = ptrace ? tnow() : 0.0;
             if (k >= kPipeSlots && !delivered.wait_for(k - kPipeSlots)) return ORBX_OK;  // the result slot has been handed over
+            const double te3 = ptrace ? tnow() : 0.0;
             HIP_TRY(c, hipStreamWaitEvent(c->st_down, c->ev_done[slot], 0));
             uint8_t* res = (uint8_t*)c->h_res[slot];
             HIP_TRY(c, hipMemcpyAsync(res, d_kps + (size_t)f0 * cap, (size_t)mk * cap * sizeof(orbx_kp), hipMemcpyDeviceToHost,
@@ -1065,7 +1095,9 @@ int extract_batch_pipelined(orbx_ctx* c, int n, const uint8_t* const* imgs, int 
                                       c->st_down));
             HIP_TRY(c, hipMemcpyAsync(res + res_kps + res_desc, d_cnt + f0, (size_t)mk * 4, hipMemcpyDeviceToHost, c->st_down));
             HIP_TRY(c, hipEventRecord(c->ev_down[slot], c->st_down));
-            if (ptrace) std::fprintf(stderr, "chunk %d enqueued %.3f\n", k, tnow() - tp0);
+            if (ptrace)
+                std::fprintf(stderr, "chunk %d enqueued %.3f (upload calls %.3f, launches %.3f, wait for the result slot %.3f, download calls %.3f)\n", k,
+                             tnow() - tp0, te1 - te0, te2 - te1, te3 - te2, tnow() - te3);
             enqueued.set(k);
         }
         return ORBX_OK;

@@ -27,10 +27,14 @@ args = (ex._ctx, n, ptrs, w, h, strides, kps.ctypes.data_as(C.c_void_p), cap, de
         cnt.ctypes.data_as(C.c_void_p))
 assert L.orbx_extract_batch(*args) == 0
 t = []
-for _ in range(5):
+calls = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+for k in range(calls):
+    sys.stderr.write("== call %d\n" % k)
+    sys.stderr.flush()
     t0 = time.perf_counter()
     assert L.orbx_extract_batch(*args) == 0
     t.append(time.perf_counter() - t0)
 best = min(t)
+print("calls (ms): " + " ".join("%.2f" % (1e3 * v) for v in t))
 print("orbx_extract_batch, %d KITTI-shape frames from/to host memory: %.2f ms -> %.0f frames/s (%.1f GB/s in)"
       % (n, best * 1e3, n / best, n * w * h / best / 1e9))
