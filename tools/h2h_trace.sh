@@ -1,5 +1,7 @@
 #!/bin/bash
-# Host batch path inside the benchmark process, per-chunk trace: without and with the copy-engine warm-up.
+# Host batch path inside the benchmark process, per-chunk trace (ORBX_TRACE=1): without and with the copy-engine warm-up.
+# The "without" build:  make -C orb_slam2_amd/csrc OUT=../liborbx_nowarm.so EXTRA=-DORBX_DIAG_NO_PIPE_WARM
+#   gpurun -- 'bash tools/h2h_trace.sh'   -> gpurun_out/r03_h2h_trace_{before,after}.txt
 G=$PWD/gpurun_out
 ORBX_LIB=orb_slam2_amd/liborbx_nowarm.so ORBX_TRACE=1 python bench.py --steps 20 --no-cpu > $G/h2h_before.json 2> $G/r03_h2h_trace_before.txt
 ORBX_TRACE=1 python bench.py --steps 20 --no-cpu > $G/h2h_after.json 2> $G/r03_h2h_trace_after.txt
