@@ -147,9 +147,9 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 // grid = (ceil(frames * ceil(dw/4) / 256), ceil(dh / rows_per_item)), block = 256.
 constexpr int kRsPF = 2;  // source rows in flight per lane (4: 3 % slower alone, 0.5 % in the overlapped step; 1, 3, 6, 8: slower as well)
 
-__device__ __forceinline__ uint32_t mul_hi_u24(uint32_t a, uint32_t b) {  // both below 2^24
+__device__ __forceinline__ uint32_t mul_hi_u24(uint32_t a, uint32_t b) {  // both below 2^24; a is wave-uniform (a scalar register operand)
     uint32_t r;
-    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b));
     return r;
 }
 
@@ -184,7 +184,10 @@ __global__ __launch_bounds__(256) void k_resize_rows(const uint8_t* __restrict__
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, (int)(splane * (uint64_t)n_frames), 0x00020000);
     const int vsrc = live ? (int)((uint64_t)f * splane) + base : kOut;
-    uint8_t* D = dst + (uint64_t)f * dplane + x0;
+    // stores through a buffer resource as well: the lane's offset is fixed, the row's offset is scalar (no 64-bit address
+    // arithmetic per row), and a lane without work is out of range instead of masked off
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(dplane * (uint64_t)n_frames), 0x00020000);
+    const int vdst = live ? (int)((uint64_t)f * dplane) + x0 : kOut;
 
     const int y0 = blockIdx.y * rows_per_item, y_end = min(y0 + rows_per_item, dh);
     // taps of the next two destination rows, fetched ahead of their use
@@ -213,7 +216,8 @@ __global__ __launch_bounds__(256) void k_resize_rows(const uint8_t* __restrict__
             // stores the compiler must wait for every outstanding load before it may read the oldest one, which
             // empties the load pipeline once per source row.
             auto emit = [&]() {
-                if ((int)(t_cur.x & 0xFFFFu) == sr) {  // both taps on one row (the clamped last rows)
+                if (__builtin_expect((int)(t_cur.x & 0xFFFFu) == sr, 0)) {  // both taps on one row (the clamped last rows)
+                    asm volatile("" ::: "memory");  // a scalar branch around four moves, not four selects on every row
 #pragma unroll
                     for (int px = 0; px < 4; ++px) Xp[px] = X[px];
                 }
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(256) void k_resize_rows(const uint8_t* __restrict__
                 // the last dword of a row is stored whole: the row pitch is a multiple of 64, the columns beyond the
                 // level's width are padding that nothing reads (they receive the last column's value), and a byte
                 // store is a partial write of its own to the memory system
-                if (live) *reinterpret_cast<uint32_t*>(D + (uint64_t)y * dpitch) = out;
+                __builtin_amdgcn_raw_buffer_store_b32(out, rd, vdst, y * dpitch, 0);
                 ++y;
                 t_cur = t_nxt;
                 t_nxt = resize_row_tap(yt, min(y + 1, dh - 1));
