@@ -660,7 +660,7 @@ int orbx_debug_read(orbx_ctx* ctx, int what, int img_idx, int level, void* dst, 
 /* Diagnostic switches.  None changes results; each lets a test or a measurement reach a path
  * ordinary inputs seldom take.  Their initial values come from the environment, read once in
  * orbx_create (ORBX_NO_OVERLAP, ORBX_RESIZE_TILES, ORBX_STEREO_BORDER_PATH, ORBX_TRACE,
- * ORBX_NO_GRAPH: set = 1; ORBX_PIPE_CHUNK=<frames>); this call changes one of them on a live
+ * ORBX_NO_GRAPH, ORBX_ORDERED: set = 1; ORBX_PIPE_CHUNK=<frames>); this call changes one of them on a live
  * context after waiting for its work in flight.  No counterpart in the reference. */
 enum {
     ORBX_FLAG_NO_OVERLAP = 1,         /* all stages on one stream, in stage order                   */
@@ -670,6 +670,8 @@ enum {
     ORBX_FLAG_NO_GRAPH = 5,           /* orbx_extract issues its launches one by one, no HIP graph   */
     ORBX_FLAG_PIPE_CHUNK = 6,         /* frames per chunk of the pipelined host batch path (0: auto) */
     ORBX_FLAG_INIT_LIST = 7,          /* candidates per list of orbx_search_for_initialization_batch_device (0: default) */
+    ORBX_FLAG_ORDERED = 9,            /* orbx_extract_batch_device: no batch's pyramid and blur run ahead of the
+                                         main stream (the order every other entry point uses)         */
     ORBX_FLAG_POISON = 8              /* test hook: from the next batch on, the device-side count of frame 0's first
                                          FAST cell (1), of its first level's retained points (2), or its first
                                          candidate point (3) is overwritten with an out-of-range value after its

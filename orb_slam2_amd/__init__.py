@@ -27,6 +27,7 @@ DBG_BLURRED, DBG_CANDIDATES, DBG_LEVEL_KPS = 1, 2, 3
 FLAG_NO_OVERLAP, FLAG_RESIZE_TILES, FLAG_STEREO_BORDER_PATH, FLAG_TRACE, FLAG_NO_GRAPH, FLAG_PIPE_CHUNK = 1, 2, 3, 4, 5, 6
 FLAG_INIT_LIST = 7
 FLAG_POISON = 8
+FLAG_ORDERED = 9
 E_DEVICE_DATA = -7
 
 

@@ -338,7 +338,10 @@ __global__ __launch_bounds__(256) void k_pad_levels(PadDev P) {
 // grid = (B.blur_first[nlevels], frames), block = 256; or, frame_major, (frames of a group of 8,
 // B.blur_first[nlevels], groups): workgroups go to the XCDs round-robin in x-fastest order, so the
 // blocks of a frame, which share halo rows and neighbour columns, then meet in one L2.
-constexpr int kBlurRows = 32;
+#ifndef ORBX_BLUR_ROWS
+#define ORBX_BLUR_ROWS 24
+#endif
+constexpr int kBlurRows = ORBX_BLUR_ROWS;
 constexpr int kBlurPF = 8;
 constexpr int kBlurItems = 4 * 62;  // (row tile, dword column) pairs per streaming block: 62 per wave
 

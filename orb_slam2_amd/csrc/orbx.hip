@@ -196,6 +196,8 @@ struct orbx_ctx {
     // count or a coordinate outside its bounds sets one; sync_ctx reads them after the streams have drained
     uint32_t* h_status = nullptr;
     uint32_t* d_status = nullptr;  // the same words as the device addresses them
+    bool main_touched = false;     // something other than a batch was put on the main stream since the last batch (or drain)
+    bool dbg_ordered = false;      // diagnostic: no batch runs ahead of the main stream (see run_batch, free_run)
     int dbg_poison = 0;            // test hook: 1 a cell count, 2 a level count, 3 a candidate point is overwritten on the device
 
     bool profiling = false;
@@ -218,6 +220,7 @@ namespace {
 // The descriptors of a batch run on their own stream (see run_batch).  join() makes everything
 // enqueued on the main stream from here on wait for them; sync_ctx() also drains the main stream.
 int join(orbx_ctx* c) {
+    c->main_touched = true;  // every caller is about to put work on the main stream (see run_batch, free_run)
     for (int i = 0; i < 2; ++i)
         if (c->desc_pending[i]) {
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_desc[i], 0));
@@ -247,6 +250,7 @@ int sync_ctx(orbx_ctx* c) {
     int rc = join(c);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->main_touched = false;  // drained
     return check_status(c);
 }
 
@@ -610,7 +614,7 @@ int ensure_aux_streams(orbx_ctx* c) {
 // Enqueues the whole path for n frames (see fill_batch) on the context's stream.
 int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_plane, orbx_kp* d_kps, int kp_cap,
               uint8_t* d_desc, int32_t* d_n_out, int arena_set, int kp_set, int n_total = -1, int frame0 = 0,
-              bool arena_known_free = false) {
+              bool arena_known_free = false, bool inputs_at_call = false) {
     fill_batch(c, n, l0, l0_pitch, l0_plane, n_total < 0 ? n : n_total, frame0, arena_set);
     c->arena_set = arena_set;
     c->kp_set = kp_set;
@@ -624,6 +628,16 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     // the other set of arenas, is detected while this one is described.
     // The no-overlap switch (ORBX_NO_OVERLAP=1) puts everything on the main stream in stage order.
     const bool overlap = !c->dbg_no_overlap;
+    // A batch whose level-0 images were complete in memory when the call was made (inputs_at_call), with nothing put on
+    // the main stream since the batch before it, need not take its place in the main stream's order before its
+    // pyramid is built: the auxiliary stream starts on it as soon as the arena set is free (the descriptors of the
+    // batch before the previous one), builds the pyramid and blurs it while the main stream still detects the batch
+    // before, and the main stream finds the pyramid ready.  Any other batch (its images come from a copy or a staging
+    // kernel on the main stream, or the main stream holds reads of the arenas) is ordered the other way: pyramid
+    // behind the main stream's position, blur behind FAST.  Measured on 512-frame batches enqueued back to back:
+    // 1.94 -> 1.87 ms per batch; with the blur moved up but the pyramid still behind the main stream, 1.96 ms.
+    const bool free_run = overlap && inputs_at_call && !c->main_touched && !c->dbg_ordered;
+    const bool pipeline_busy = c->desc_pending[0] || c->desc_pending[1];
     hipStream_t st = c->stream;
     if (overlap) { int rc_ = ensure_aux_streams(c); if (rc_) return rc_; }
     hipStream_t aux = overlap ? c->st_aux : st;
@@ -656,8 +670,11 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     };
     if (overlap) {
         // level 0 and the arenas are ready when the main stream gets here
-        HIP_TRY(c, hipEventRecord(c->ev_start, st));
-        HIP_TRY(c, hipStreamWaitEvent(aux, c->ev_start, 0));
+        if (!free_run) {
+            HIP_TRY(c, hipEventRecord(c->ev_start, st));
+            HIP_TRY(c, hipStreamWaitEvent(aux, c->ev_start, 0));
+        }
+        c->main_touched = false;  // whatever was put on the main stream so far is in front of this batch, and of every later one
         // the pyramid and the blur overwrite this arena set: its last reader must have finished
         if (!arena_known_free && (rc = wait_arena_free(c, arena_set, aux))) return rc;
     }
@@ -696,8 +713,14 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
             // destination rows per lane: long bands filter fewer source rows twice, short ones give
             // the small levels enough waves to hide their load latency
             const unsigned blocks_x = ((unsigned)n * nd + 255) / 256;
-            int rows = 32;
-            while (rows > 8 && (uint64_t)blocks_x * 4 * ((D.h + rows - 1) / rows) < 16384) rows >>= 1;
+#ifndef ORBX_RS_ROWS
+#define ORBX_RS_ROWS 32
+#endif
+            int rows = ORBX_RS_ROWS;
+#ifndef ORBX_RS_WAVES
+#define ORBX_RS_WAVES 4096
+#endif
+            while (rows > 8 && (uint64_t)blocks_x * 4 * ((D.h + rows - 1) / rows) < ORBX_RS_WAVES) rows >>= 1;
             dim3 grid_rows(blocks_x, (D.h + rows - 1) / rows);
             hipLaunchKernelGGL(k_resize_rows, grid_rows, dim3(256), 0, aux, S.img, S.pitch, S.plane, const_cast<uint8_t*>(D.img),
                                D.pitch, D.plane, D.w, D.h, (const ResizeTap*)c->d_xt[l].p, (const ResizeTap*)c->d_yt[l].p, n,
@@ -718,11 +741,15 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     // quadtree of the batch before the previous one may still be reading.
     if (overlap && c->oct_pending[kp_set]) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_oct_set[kp_set], 0));
     if ((rc = mark(kEvFastA0, st))) return rc;
-    launch_fast(0, overlap ? n_tiles0 : 0);
+    // Level 0 needs no pyramid and goes first, the other levels when the pyramid is there.  A free-running batch behind
+    // another one finds its pyramid built long before the main stream gets to it: one launch for all levels then
+    // (0.7 % of the step: no drained GPU between the two launches).
+    const bool split = overlap && !(free_run && pipeline_busy);
+    launch_fast(0, split ? n_tiles0 : 0);
     if ((rc = mark(kEvFastA1, st))) return rc;
     if (overlap) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_pyr_done, 0));
     if ((rc = mark(kEvFastB0, st))) return rc;
-    launch_fast(overlap ? n_tiles0 : 0, overlap ? n_tiles - n_tiles0 : n_tiles);
+    launch_fast(split ? n_tiles0 : 0, split ? n_tiles - n_tiles0 : n_tiles);
     if ((rc = mark(kEvFastB1, st))) return rc;
     // test hook (orbx_set_debug_flag, ORBX_FLAG_POISON): what the detector left for frame 0, cell 0 is overwritten,
     // so that a test can see the consumers of device-side counts cut them to their bounds and report them
@@ -736,7 +763,7 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
         // it only slows FAST down (both are bound by vector instruction issue), started here it runs
         // beside the quadtree and the descriptor stage, which leave the vector units idle.
         HIP_TRY(c, hipEventRecord(c->ev_fast_done, st));
-        HIP_TRY(c, hipStreamWaitEvent(aux, c->ev_fast_done, 0));
+        if (!free_run) HIP_TRY(c, hipStreamWaitEvent(aux, c->ev_fast_done, 0));
         if ((rc = mark(kEvBlur0, aux))) return rc;
         hipLaunchKernelGGL(k_blur7_all, blur_grid, dim3(256), 0, aux, B, blur_fm ? 1 : 0);
         if ((rc = mark(kEvBlur1, aux))) return rc;
@@ -1304,6 +1331,7 @@ extern "C" int orbx_create(const orbx_params* params, orbx_ctx** out) {
     c->dbg_stereo_border = std::getenv("ORBX_STEREO_BORDER_PATH") != nullptr;
     c->dbg_trace = std::getenv("ORBX_TRACE") != nullptr;
     c->dbg_no_graph = std::getenv("ORBX_NO_GRAPH") != nullptr;
+    c->dbg_ordered = std::getenv("ORBX_ORDERED") != nullptr;
 #ifdef ORBX_DIAG_LOW_PRIORITY
     c->dbg_aux_low_priority = std::getenv("ORBX_AUX_LOW_PRIORITY") != nullptr;
 #endif
@@ -1423,13 +1451,14 @@ extern "C" int orbx_extract_batch_device(orbx_ctx* c, int n, const uint8_t* d_im
     const int aset = c->arena_set ^ 1, kset = c->kp_set ^ 1;
     if (!in_place) {
         if ((rc = wait_arena_free(c, aset, c->stream))) return rc;  // level 0 of this set may still be read by descriptors
+        c->main_touched = true;
         for (int i = 0; i < n; ++i)
             HIP_TRY(c, hipMemcpy2DAsync((uint8_t*)c->d_pyr[aset].p + (size_t)i * c->plane[0], c->pitch[0],
                                         d_imgs + (size_t)i * frame_stride, stride, width, height,
                                         hipMemcpyDeviceToDevice, c->stream));
         rc = run_batch(c, n, nullptr, 0, 0, d_kps, kp_cap, d_desc, d_n_out, aset, kset);
     } else {
-        rc = run_batch(c, n, d_imgs, stride, frame_stride, d_kps, kp_cap, d_desc, d_n_out, aset, kset);
+        rc = run_batch(c, n, d_imgs, stride, frame_stride, d_kps, kp_cap, d_desc, d_n_out, aset, kset, -1, 0, false, true);
     }
     if (rc) return rc;
     if (sync) { int rc_ = sync_ctx(c); if (rc_) return rc_; }
@@ -2376,6 +2405,7 @@ extern "C" int orbx_set_debug_flag(orbx_ctx* c, int flag, int value) {
         case ORBX_FLAG_NO_GRAPH: c->dbg_no_graph = value != 0; break;
         case ORBX_FLAG_PIPE_CHUNK: c->dbg_pipe_chunk = std::max(0, value); break;
         case ORBX_FLAG_INIT_LIST: c->dbg_init_list = std::max(0, std::min(value, kInitListCap)); break;
+        case ORBX_FLAG_ORDERED: c->dbg_ordered = value != 0; break;
         case ORBX_FLAG_POISON: c->dbg_poison = (value >= 0 && value <= 3) ? value : 0; break;
         default: return ORBX_E_INVALID;
     }

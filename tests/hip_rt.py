@@ -45,6 +45,11 @@ class DeviceArray:
         assert rt().hipMemcpy(out.ctypes.data, self.ptr, self.nbytes, 2) == 0  # hipMemcpyDeviceToHost
         return out
 
+    def fill(self, byte):
+        """Sets every byte; returns when the device has done it."""
+        assert rt().hipMemset(self.ptr, byte, self.nbytes) == 0
+        assert rt().hipDeviceSynchronize() == 0
+
     def free(self):
         if self.ptr:
             rt().hipFree(self.ptr)

@@ -297,6 +297,64 @@ def test_back_to_back_async_batches(oracle):
             a.free()
 
 
+def test_free_running_batches_mixed_with_staging_calls(oracle):
+    """Batches whose images are resident when the call is made build their pyramid ahead of the main stream;
+    a batch whose images a staging call on the same context has just produced (orbx_gray_batch_device) must
+    not, and neither must the batches around a call that reads the arenas from the main stream (stereo
+    association of the previous batch).  All of them are enqueued without waiting; the results must equal
+    those of the same calls made one at a time, and those of the ordered schedule (ORBX_FLAG_ORDERED)."""
+    from hip_rt import DeviceArray
+    w, h, nf, nl, n = 640, 480, 1000, 8, 8
+    ex = oa.ORBextractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=n, keep_pyramid=False)
+    cap = ex.max_keypoints(w, h)
+    gray = [synth.make_batch(n, w, h, 4, 900 + 13 * b) for b in range(4)]
+    rgb = np.repeat(gray[2][..., None], 3, axis=3)          # R = G = B: the conversion returns the grey value
+    d_gray = [DeviceArray.from_host(g) for g in gray]
+    d_rgb = DeviceArray.from_host(rgb)
+    d_conv = DeviceArray((n, h, w), np.uint8, fill_byte=0)
+    d_u = DeviceArray((n // 2, cap), np.float32, fill_byte=0)
+    d_z = DeviceArray((n // 2, cap), np.float32, fill_byte=0)
+
+    def run(wait):
+        outs = [(DeviceArray((n, cap, 28), np.uint8, fill_byte=0), DeviceArray((n, cap, 32), np.uint8, fill_byte=0),
+                 DeviceArray((n,), np.int32, fill_byte=0)) for _ in range(6)]
+        def batch(i, ptr):
+            k, q, c = outs[i]
+            ex.extract_batch_device(ptr, n, w, h, w, h * w, k.ptr, cap, q.ptr, c.ptr, sync=wait)
+        d_conv.fill(0)
+        batch(0, d_gray[0].ptr)
+        batch(1, d_gray[1].ptr)
+        ex.gray_batch_device(n, d_rgb.ptr, w, h, 3 * w, 3 * w * h, 3, 0, d_conv.ptr, w, w * h, sync=wait)
+        batch(2, d_conv.ptr)                                 # its images come from the kernel in front of it
+        batch(3, d_gray[3].ptr)
+        k, q, c = outs[3]
+        ex.stereo_match_batch_device(n // 2, k.ptr, cap, q.ptr, c.ptr, 0.5, 400.0, d_u.ptr, d_z.ptr, sync=wait)
+        batch(4, d_gray[0].ptr)                              # the next two reuse the arenas the association reads
+        batch(5, d_gray[1].ptr)
+        ex.synchronize()
+        res = [tuple(a.to_host() for a in t) for t in outs] + [(d_u.to_host(), d_z.to_host())]
+        for t in outs:
+            for a in t:
+                a.free()
+        return res
+
+    ref = run(True)
+    for ordered in (0, 1, 0):
+        ex.set_debug_flag(oa.FLAG_ORDERED, ordered)
+        got = run(False)
+        for r, g in zip(ref, got):
+            for a, b in zip(r, g):
+                assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), ordered
+    orc = oracle.Oracle(nf, 1.2, nl, 20, 7)
+    kps, desc, cnt = ref[2]
+    okps, odesc = orc.extract(gray[2][3])
+    assert cnt[3] == len(okps)
+    _check_final(np.ascontiguousarray(kps[3, :cnt[3]]).reshape(-1).view(oa.KP_DTYPE), desc[3, :cnt[3]], okps, odesc)
+    ex.close()
+    for a in d_gray + [d_rgb, d_conv, d_u, d_z]:
+        a.free()
+
+
 def test_dotted_images(oracle):
     """Single-pixel dots on a flat ground: few pixels pass the rejection test but most of those are
     corners, so a tile's corner list runs from nearly empty to over its capacity (step 3 of the FAST
