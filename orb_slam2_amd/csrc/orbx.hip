@@ -91,6 +91,8 @@ struct DevBuf {
 
 }  // namespace
 
+constexpr int kArenaSets = 2;  // pyramid + blur arenas a context alternates between
+
 enum {  // timing events of one batch
     kEvPyr0, kEvPyr1, kEvFastA0, kEvFastA1, kEvFastB0, kEvFastB1, kEvOct0, kEvOct1, kEvBlur0, kEvBlur1, kEvDesc0, kEvDesc1, kEvCount
 };
@@ -122,14 +124,14 @@ struct orbx_ctx {
     // device arenas (grown on demand)
     // Two sets of everything the descriptor stage reads (pyramid, blurred pyramid, retained points):
     // the descriptors of one batch run while the next batch is detected into the other set.
-    DevBuf d_pyr[2], d_blur[2], d_lvl_kps[2], d_lvl_count[2];
+    DevBuf d_pyr[kArenaSets], d_blur[kArenaSets], d_lvl_kps[2], d_lvl_count[2];
     DevBuf d_cand[2], d_ccount[2];  // FAST output, alternating like the retained points (index kp_set)
     DevBuf d_dense_pts, d_dense_node;
     DevBuf d_oct_ws;          // quadtree tables of quotas that do not fit the LDS (oct_global), per (frame, level)
     bool oct_global = false;
     size_t oct_ws_stride = 0;
     int arena_set = 0, kp_set = 0;            // sets of the last batch
-    int arena_desc[2] = {-1, -1};             // descriptor event (index into ev_desc) last reading each arena set
+    bool arena_pending[kArenaSets] = {};      // ev_arena[i] recorded (behind the descriptors that last read arena set i) and not yet drained
     bool desc_pending[2] = {false, false};    // ev_desc[i] recorded and not yet joined
     bool oct_pending[2] = {false, false};     // ev_oct_set[i] recorded and not yet joined
     DevBuf d_out_kps, d_out_desc, d_out_n;  // results of the host-memory entry points
@@ -159,7 +161,7 @@ struct orbx_ctx {
     hipStream_t st_aux = nullptr;
     hipStream_t st_desc = nullptr;            // descriptor stage
     hipStream_t st_oct = nullptr;             // quadtree stage
-    hipEvent_t ev_start, ev_pyr_done, ev_fast_done, ev_blur_done, ev_oct_done, ev_desc[2], ev_oct_set[2];
+    hipEvent_t ev_start, ev_pyr_done, ev_fast_done, ev_blur_done, ev_oct_done, ev_desc[2], ev_oct_set[2], ev_arena[kArenaSets];
     bool aux_made = false;
     int tiles_level0 = 0;  // the first tiles_level0 entries of `tiles` belong to level 0
     // stereo stage scratch (grown on demand)
@@ -231,8 +233,7 @@ int join(orbx_ctx* c) {
 }
 // `stream` waits until the descriptor stage that last read arena set `set` has finished.
 int wait_arena_free(orbx_ctx* c, int set, hipStream_t stream) {
-    const int e = c->arena_desc[set];
-    if (e >= 0 && c->desc_pending[e]) HIP_TRY(c, hipStreamWaitEvent(stream, c->ev_desc[e], 0));
+    if (c->arena_pending[set]) HIP_TRY(c, hipStreamWaitEvent(stream, c->ev_arena[set], 0));
     return ORBX_OK;
 }
 // Non-zero status words = some kernel since the last check read a value outside its bounds from device memory (it
@@ -251,6 +252,7 @@ int sync_ctx(orbx_ctx* c) {
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->main_touched = false;  // drained
+    for (bool& p : c->arena_pending) p = false;
     return check_status(c);
 }
 
@@ -505,9 +507,11 @@ int ensure_arenas(orbx_ctx* c, int n, bool need_level0) {
         blur += c->plane[l] * n;
     }
     int rc;
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < kArenaSets; ++k) {
         if ((rc = ensure(c, &c->d_pyr[k], pyr))) return rc;
         if ((rc = ensure(c, &c->d_blur[k], blur))) return rc;
+    }
+    for (int k = 0; k < 2; ++k) {
         if ((rc = ensure(c, &c->d_lvl_kps[k], (size_t)n * c->kp_total * 4))) return rc;
         if ((rc = ensure(c, &c->d_lvl_count[k], (size_t)n * c->tab.nlevels * 4))) return rc;
     }
@@ -604,6 +608,7 @@ int ensure_aux_streams(orbx_ctx* c) {
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_oct_done, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_desc[0], hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_desc[1], hipEventDisableTiming));
+    for (int i = 0; i < kArenaSets; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_arena[i], hipEventDisableTiming));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->st_oct, hipStreamNonBlocking));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_oct_set[0], hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_oct_set[1], hipEventDisableTiming));
@@ -828,7 +833,8 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     if (overlap) {
         HIP_TRY(c, hipEventRecord(c->ev_desc[kp_set], sd));
         c->desc_pending[kp_set] = true;
-        c->arena_desc[arena_set] = kp_set;
+        HIP_TRY(c, hipEventRecord(c->ev_arena[arena_set], sd));
+        c->arena_pending[arena_set] = true;
     }
     if (prof) c->ev_valid = true;
     HIP_TRY(c, hipGetLastError());
@@ -1182,7 +1188,7 @@ int build_graph(orbx_ctx* c, const GraphWant& g) {
     HIP_TRY(c, hipHostMalloc(&c->h_gin, plane * g.n, hipHostMallocDefault));
     HIP_TRY(c, hipHostMalloc(&c->h_gout, out_bytes, hipHostMallocDefault));
     std::memset(c->h_gin, 0, plane * g.n);
-    c->arena_desc[0] = c->arena_desc[1] = -1;
+    for (bool& p : c->arena_pending) p = false;
     hipGraph_t graph = nullptr;
     HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     c->capturing = true;
@@ -1216,7 +1222,7 @@ int build_graph(orbx_ctx* c, const GraphWant& g) {
     c->capturing = false;
     c->desc_pending[0] = c->desc_pending[1] = false;
     c->oct_pending[0] = c->oct_pending[1] = false;
-    c->arena_desc[0] = c->arena_desc[1] = -1;
+    for (bool& p : c->arena_pending) p = false;
     c->have_last = false;  // nothing has run yet
     if (rc == ORBX_OK && e_end != hipSuccess) {
         c->last_hip = (int)e_end;
@@ -1415,6 +1421,7 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
         (void)hipEventDestroy(c->ev_oct_done);
         (void)hipEventDestroy(c->ev_desc[0]);
         (void)hipEventDestroy(c->ev_desc[1]);
+        for (int i = 0; i < kArenaSets; ++i) (void)hipEventDestroy(c->ev_arena[i]);
         (void)hipEventDestroy(c->ev_oct_set[0]);
         (void)hipEventDestroy(c->ev_oct_set[1]);
         (void)hipStreamDestroy(c->st_oct);
@@ -1447,6 +1454,8 @@ extern "C" int orbx_extract_batch_device(orbx_ctx* c, int n, const uint8_t* d_im
     int rc = check_call(c, n, width, height, kp_cap);
     if (rc) return rc;
     const bool in_place = ((uintptr_t)d_imgs % 4 == 0) && (stride % 4 == 0) && (frame_stride % 4 == 0);
+    // (Three arena sets in turn, so that a batch's pyramid and blur need not wait for the descriptors of the batch
+    // before the previous one, which run at that very time: 1.865 against 1.863 ms per batch, nothing.)
     if ((rc = ensure_arenas(c, n, !in_place))) return rc;
     const int aset = c->arena_set ^ 1, kset = c->kp_set ^ 1;
     if (!in_place) {
