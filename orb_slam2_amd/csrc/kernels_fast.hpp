@@ -282,81 +282,96 @@ __device__ __forceinline__ void fast_pass(const uint8_t* s_tile, uint8_t* s_scor
     const int n_items = hd * ndw, vp = fast_verdict_pitch(wd);
     // bias that moves "difference >= 256 t + 1" into a lane's bit 15 (t above 127 is tested as 127: still a filter)
     const uint32_t k_bias = (uint32_t)(0x8000 - (256 * min(thr, 127) + 1)) * 0x00010001u;
-    // (row, dword) of item tid, advanced by 256 items per iteration without divisions; the item's place in
-    // the tile (row v - 3, the dword left of the item's) and in the verdict plane move along by additions
-    const float inv_ndw = fast_rcp(ndw);
-    const int v0 = (int)(((float)tid + 0.5f) * inv_ndw);
-    int j = tid - v0 * ndw;  // relative to j_lo
-    const int dv = (int)(256.5f * inv_ndw), dj = 256 - dv * ndw;  // 256 / ndw and 256 % ndw
-    const uint8_t* pw = s_tile + v0 * TP + 4 * (j + j_lo);
-    uint8_t* pv = s_verdict + v0 * vp + j + j_lo;
-    // steps of the two places: without and with a wrap into the next row (selected per lane, no branch)
-    const int da_t = dv * TP + 4 * dj, da_v = dv * vp + dj, da_tw = da_t + TP - 4 * ndw, da_vw = da_v + vp - ndw;
-    for (int i0 = 0; i0 < n_items; i0 += 256) {
+    // The test of one work item: pw = the tile's row v - 3 at the dword left of the item's, pv = the item's verdict
+    // byte, jd = the item's dword column in the tile (only the retry reads it).
+    auto test_item = [&](const uint8_t* pw, uint8_t* pv, int jd) {
+        (void)jd;
         uint32_t pb[2], pd[2];  // [0]: bits 15/31 = pixels 0/2, [1]: pixels 1/3
-        // items past the end (last iteration only) do nothing
-        if (tid < n_items - i0) {
-            // the dwords of the item's columns (c), of the four columns before (p) and after (n), rows -3 .. +3
-            const uint32_t Cc = *reinterpret_cast<const uint32_t*>(pw + 3 * TP + 4), Cp = *reinterpret_cast<const uint32_t*>(pw + 3 * TP),
-                           Cn = *reinterpret_cast<const uint32_t*>(pw + 3 * TP + 8);
-            const uint32_t Ud = *reinterpret_cast<const uint32_t*>(pw + 6 * TP + 4), Dd = *reinterpret_cast<const uint32_t*>(pw + 4);
-            const uint32_t P2c = *reinterpret_cast<const uint32_t*>(pw + 5 * TP + 4), P2p = *reinterpret_cast<const uint32_t*>(pw + 5 * TP),
-                           P2n = *reinterpret_cast<const uint32_t*>(pw + 5 * TP + 8);
-            const uint32_t M2c = *reinterpret_cast<const uint32_t*>(pw + TP + 4), M2p = *reinterpret_cast<const uint32_t*>(pw + TP),
-                           M2n = *reinterpret_cast<const uint32_t*>(pw + TP + 8);
-            uint32_t on[2] = {0x80008000u, 0x80008000u};
-            if (RETRY) {
+        // the dwords of the item's columns (c), of the four columns before (p) and after (n), rows -3 .. +3
+        const uint32_t Cc = *reinterpret_cast<const uint32_t*>(pw + 3 * TP + 4), Cp = *reinterpret_cast<const uint32_t*>(pw + 3 * TP),
+                       Cn = *reinterpret_cast<const uint32_t*>(pw + 3 * TP + 8);
+        const uint32_t Ud = *reinterpret_cast<const uint32_t*>(pw + 6 * TP + 4), Dd = *reinterpret_cast<const uint32_t*>(pw + 4);
+        const uint32_t P2c = *reinterpret_cast<const uint32_t*>(pw + 5 * TP + 4), P2p = *reinterpret_cast<const uint32_t*>(pw + 5 * TP),
+                       P2n = *reinterpret_cast<const uint32_t*>(pw + 5 * TP + 8);
+        const uint32_t M2c = *reinterpret_cast<const uint32_t*>(pw + TP + 4), M2p = *reinterpret_cast<const uint32_t*>(pw + TP),
+                       M2n = *reinterpret_cast<const uint32_t*>(pw + TP + 8);
+        uint32_t on[2] = {0x80008000u, 0x80008000u};
+        if (RETRY) {
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int u = min(4 * (j + j_lo) + b, wd - 1);
-                    if (sh->th[min((int)(((float)u + 0.5f) * inv_wcell), nc - 1)] < 0) on[b & 1] &= ~(0x8000u << (8 * (b & 2)));
-                }
+            for (int b = 0; b < 4; ++b) {
+                const int u = min(4 * jd + b, wd - 1);
+                if (sh->th[min((int)(((float)u + 0.5f) * inv_wcell), nc - 1)] < 0) on[b & 1] &= ~(0x8000u << (8 * (b & 2)));
             }
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {  // 0: pixels 0, 2   1: pixels 1, 3
-                // every operand is a dword whose bytes 1 and 3 are the ring pixels of the two pixels under test:
-                // v_alignbyte_b32 of two neighbouring dwords (pixels +-3 on the row, +-2 on the rows +-2), the
-                // dword itself or the dword shifted by one byte (centre, rows +-3)
-                uint32_t c, u, d, r, l, pp, mp, pm, mm;
-                if (h2) {
-                    c = Cc, u = Ud, d = Dd;
-                    r = __builtin_amdgcn_alignbyte(Cn, Cc, 3), l = __builtin_amdgcn_alignbyte(Cc, Cp, 1);
-                    pp = __builtin_amdgcn_alignbyte(P2n, P2c, 2), mp = __builtin_amdgcn_alignbyte(P2c, P2p, 2);
-                    pm = __builtin_amdgcn_alignbyte(M2n, M2c, 2), mm = __builtin_amdgcn_alignbyte(M2c, M2p, 2);
-                } else {
-                    c = Cc << 8, u = Ud << 8, d = Dd << 8;
-                    r = __builtin_amdgcn_alignbyte(Cn, Cc, 2), l = Cp;
-                    pp = __builtin_amdgcn_alignbyte(P2n, P2c, 1), mp = __builtin_amdgcn_alignbyte(P2c, P2p, 1);
-                    pm = __builtin_amdgcn_alignbyte(M2n, M2c, 1), mm = __builtin_amdgcn_alignbyte(M2c, M2p, 1);
-                }
-                // ring darker on all four pairs: centre - max(min(u,d), min(l,r), min(pp,mm), min(pm,mp)) > t;
-                // ring brighter: min(max(u,d), ...) - centre > t
-                uint32_t hi = pk_max_u16(pk_min_u16(u, d), pk_min_u16(l, r));
-                uint32_t lo = pk_min_u16(pk_max_u16(u, d), pk_max_u16(l, r));
-                hi = pk_max_u16(hi, pk_max_u16(pk_min_u16(pp, mm), pk_min_u16(pm, mp)));
-                lo = pk_min_u16(lo, pk_min_u16(pk_max_u16(pp, mm), pk_max_u16(pm, mp)));
-                pb[h2] = pk_add_sat_u16(pk_sub_sat_u16(c, hi), k_bias);  // only bits 15 and 31 are read
-                pd[h2] = pk_add_sat_u16(pk_sub_sat_u16(lo, c), k_bias);
-                if (RETRY) {
-                    pb[h2] &= on[h2];
-                    pd[h2] &= on[h2];
-                }
-            }
-            // Verdict byte of the work item: bit 2p + 1 = ring darker, bit 2p = ring brighter for pixel p of the
-            // dword.  One v_perm_b32 per side gathers the four flag bytes, pixel 3 first; three bit-field inserts
-            // fold the four bit pairs into the low byte (the other bits of the operands are never read).
-            const uint32_t Bm = __builtin_amdgcn_perm(pb[1], pb[0], 0x01050307u);
-            const uint32_t Dm = __builtin_amdgcn_perm(pd[1], pd[0], 0x01050307u);
-            uint32_t t = bfi(0x80808080u, Bm, Dm >> 1);  // bits 7, 6 of every byte
-            t = bfi(0xC0C0C0C0u, t, t >> 10);          // bytes 0 and 2: pairs at bits 7..4
-            t = bfi(0x000000F0u, t, t >> 20);          // byte 0: all four pairs
-            *pv = (uint8_t)t;
         }
-        j += dj;
-        const bool wrap = j >= ndw;
-        j -= wrap ? ndw : 0;
-        pw += wrap ? da_tw : da_t;
-        pv += wrap ? da_vw : da_v;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {  // 0: pixels 0, 2   1: pixels 1, 3
+            // every operand is a dword whose bytes 1 and 3 are the ring pixels of the two pixels under test:
+            // v_alignbyte_b32 of two neighbouring dwords (pixels +-3 on the row, +-2 on the rows +-2), the
+            // dword itself or the dword shifted by one byte (centre, rows +-3)
+            uint32_t c, u, d, r, l, pp, mp, pm, mm;
+            if (h2) {
+                c = Cc, u = Ud, d = Dd;
+                r = __builtin_amdgcn_alignbyte(Cn, Cc, 3), l = __builtin_amdgcn_alignbyte(Cc, Cp, 1);
+                pp = __builtin_amdgcn_alignbyte(P2n, P2c, 2), mp = __builtin_amdgcn_alignbyte(P2c, P2p, 2);
+                pm = __builtin_amdgcn_alignbyte(M2n, M2c, 2), mm = __builtin_amdgcn_alignbyte(M2c, M2p, 2);
+            } else {
+                c = Cc << 8, u = Ud << 8, d = Dd << 8;
+                r = __builtin_amdgcn_alignbyte(Cn, Cc, 2), l = Cp;
+                pp = __builtin_amdgcn_alignbyte(P2n, P2c, 1), mp = __builtin_amdgcn_alignbyte(P2c, P2p, 1);
+                pm = __builtin_amdgcn_alignbyte(M2n, M2c, 1), mm = __builtin_amdgcn_alignbyte(M2c, M2p, 1);
+            }
+            // ring darker on all four pairs: centre - max(min(u,d), min(l,r), min(pp,mm), min(pm,mp)) > t;
+            // ring brighter: min(max(u,d), ...) - centre > t
+            uint32_t hi = pk_max_u16(pk_min_u16(u, d), pk_min_u16(l, r));
+            uint32_t lo = pk_min_u16(pk_max_u16(u, d), pk_max_u16(l, r));
+            hi = pk_max_u16(hi, pk_max_u16(pk_min_u16(pp, mm), pk_min_u16(pm, mp)));
+            lo = pk_min_u16(lo, pk_min_u16(pk_max_u16(pp, mm), pk_max_u16(pm, mp)));
+            pb[h2] = pk_add_sat_u16(pk_sub_sat_u16(c, hi), k_bias);  // only bits 15 and 31 are read
+            pd[h2] = pk_add_sat_u16(pk_sub_sat_u16(lo, c), k_bias);
+            if (RETRY) {
+                pb[h2] &= on[h2];
+                pd[h2] &= on[h2];
+            }
+        }
+        // Verdict byte of the work item: bit 2p + 1 = ring darker, bit 2p = ring brighter for pixel p of the
+        // dword.  One v_perm_b32 per side gathers the four flag bytes, pixel 3 first; three bit-field inserts
+        // fold the four bit pairs into the low byte (the other bits of the operands are never read).
+        const uint32_t Bm = __builtin_amdgcn_perm(pb[1], pb[0], 0x01050307u);
+        const uint32_t Dm = __builtin_amdgcn_perm(pd[1], pd[0], 0x01050307u);
+        uint32_t t = bfi(0x80808080u, Bm, Dm >> 1);  // bits 7, 6 of every byte
+        t = bfi(0xC0C0C0C0u, t, t >> 10);          // bytes 0 and 2: pairs at bits 7..4
+        t = bfi(0x000000F0u, t, t >> 20);          // byte 0: all four pairs
+        *pv = (uint8_t)t;
+    };
+    if (ndw <= 32) {
+        // A tile row of at most 32 work items (four cells of up to 31 pixels: most tiles): each half of a wave takes
+        // one row, lane by lane, and the four waves go down the tile eight rows at a time.  The item's places then
+        // move by constants and a row's 32 dword reads fall on 32 different banks; nothing wraps.
+        const int col = lane & 31, r0 = 2 * (tid >> 6) + (lane >> 5);
+        if (col < ndw) {
+            const uint8_t* pw = s_tile + r0 * TP + 4 * (col + j_lo);
+            uint8_t* pv = s_verdict + r0 * vp + col + j_lo;
+            for (int r = r0; r < hd; r += 8, pw += 8 * TP, pv += 8 * vp) test_item(pw, pv, col + j_lo);
+        }
+    } else {
+        // (row, dword) of item tid, advanced by 256 items per iteration without divisions; the item's place in
+        // the tile (row v - 3, the dword left of the item's) and in the verdict plane move along by additions
+        const float inv_ndw = fast_rcp(ndw);
+        const int v0 = (int)(((float)tid + 0.5f) * inv_ndw);
+        int j = tid - v0 * ndw;  // relative to j_lo
+        const int dv = (int)(256.5f * inv_ndw), dj = 256 - dv * ndw;  // 256 / ndw and 256 % ndw
+        const uint8_t* pw = s_tile + v0 * TP + 4 * (j + j_lo);
+        uint8_t* pv = s_verdict + v0 * vp + j + j_lo;
+        // steps of the two places: without and with a wrap into the next row (selected per lane, no branch)
+        const int da_t = dv * TP + 4 * dj, da_v = dv * vp + dj, da_tw = da_t + TP - 4 * ndw, da_vw = da_v + vp - ndw;
+        for (int i0 = 0; i0 < n_items; i0 += 256) {
+            if (tid < n_items - i0) test_item(pw, pv, j + j_lo);  // items past the end (last iteration only) do nothing
+            j += dj;
+            const bool wrap = j >= ndw;
+            j -= wrap ? ndw : 0;
+            pw += wrap ? da_tw : da_t;
+            pv += wrap ? da_vw : da_v;
+        }
     }
     __syncthreads();
     // ---- 1b. the verdict plane becomes the queue ----
