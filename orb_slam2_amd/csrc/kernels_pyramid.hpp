@@ -342,7 +342,10 @@ __global__ __launch_bounds__(256) void k_pad_levels(PadDev P) {
 #define ORBX_BLUR_ROWS 24
 #endif
 constexpr int kBlurRows = ORBX_BLUR_ROWS;
-constexpr int kBlurPF = 8;
+#ifndef ORBX_BLUR_PF
+#define ORBX_BLUR_PF 8
+#endif
+constexpr int kBlurPF = ORBX_BLUR_PF;
 constexpr int kBlurItems = 4 * 62;  // (row tile, dword column) pairs per streaming block: 62 per wave
 
 // Column pass for one pixel at row r.  pr[j % 6] holds the row sums of rows (j, j+1) packed as
