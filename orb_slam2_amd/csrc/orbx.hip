@@ -643,6 +643,12 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     // 1.94 -> 1.87 ms per batch; with the blur moved up but the pyramid still behind the main stream, 1.96 ms.
     const bool free_run = overlap && inputs_at_call && !c->main_touched && !c->dbg_ordered;
     const bool pipeline_busy = c->desc_pending[0] || c->desc_pending[1];
+    // A quadtree of 1024-thread workgroups with the node tables of a level of more than a thousand features in LDS (4K
+    // frames: most of a CU's 160 KB) finds no room on a CU while FAST's four-wave, 18 KB workgroups keep arriving:
+    // beside FAST it crawls until FAST's grid is exhausted, and everything behind it (the descriptors, the arena set,
+    // the next pyramid, the next FAST) waits.  With such a quadtree the previous batch's quadtree goes before this
+    // batch's FAST, and this batch's pyramid runs beside it.  128 4K frames per step: 9.5 -> 9.1 ms.
+    const bool wide_octree = c->oct_global || c->max_kp_level > kOctWideFrom;
     hipStream_t st = c->stream;
     if (overlap) { int rc_ = ensure_aux_streams(c); if (rc_) return rc_; }
     hipStream_t aux = overlap ? c->st_aux : st;
@@ -675,7 +681,9 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     };
     if (overlap) {
         // level 0 and the arenas are ready when the main stream gets here
-        if (!free_run) {
+        // (a batch with a wide quadtree, below: its pyramid starts when the previous batch's FAST has finished, beside that
+        // batch's quadtree, which leaves the memory system idle)
+        if (!free_run || wide_octree) {
             HIP_TRY(c, hipEventRecord(c->ev_start, st));
             HIP_TRY(c, hipStreamWaitEvent(aux, c->ev_start, 0));
         }
@@ -745,6 +753,7 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     // stage 1 (main): FAST cells, level 0 first.  It overwrites the candidate lists of set kp_set, which the
     // quadtree of the batch before the previous one may still be reading.
     if (overlap && c->oct_pending[kp_set]) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_oct_set[kp_set], 0));
+    if (overlap && wide_octree && c->oct_pending[kp_set ^ 1]) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_oct_set[kp_set ^ 1], 0));
     if ((rc = mark(kEvFastA0, st))) return rc;
     // Level 0 needs no pyramid and goes first, the other levels when the pyramid is there.  A free-running batch behind
     // another one finds its pyramid built long before the main stream gets to it: one launch for all levels then
@@ -1455,7 +1464,7 @@ extern "C" int orbx_extract_batch_device(orbx_ctx* c, int n, const uint8_t* d_im
     if (rc) return rc;
     const bool in_place = ((uintptr_t)d_imgs % 4 == 0) && (stride % 4 == 0) && (frame_stride % 4 == 0);
     // (Three arena sets in turn, so that a batch's pyramid and blur need not wait for the descriptors of the batch
-    // before the previous one, which run at that very time: 1.865 against 1.863 ms per batch, nothing.)
+    // before the previous one: 1.865 against 1.863 ms per 512 KITTI frames, 9.10 against 9.13 ms per 128 4K frames.)
     if ((rc = ensure_arenas(c, n, !in_place))) return rc;
     const int aset = c->arena_set ^ 1, kset = c->kp_set ^ 1;
     if (!in_place) {
