@@ -164,6 +164,10 @@ __global__ __launch_bounds__(256) void k_resize_rows(const uint8_t* __restrict__
                                                      uint8_t* __restrict__ dst, int dpitch, uint64_t dplane, int dw, int dh,
                                                      const ResizeTap* __restrict__ xt, const ResizeTap* __restrict__ yt,
                                                      int n_frames, int rows_per_item) {
+    // 64 registers allocated although 29 are used: the waves of FAST, the blur and the descriptor kernel, which share
+    // the SIMDs with this one, take 64 each, and a retiring 32-register wave leaves a hole none of them fits into
+    // (0.5 % of the step; the occupancy limit of 8 waves per SIMD is the same either way).
+    asm volatile("" ::: "v63");
     const int nd = (dw + 3) >> 2;
     const int item = blockIdx.x * 256 + threadIdx.x;
     const bool live = item < n_frames * nd;
