@@ -188,8 +188,13 @@ int orbx_pool_extract_stream(orbx_pool* pool, int n, const uint8_t* const* imgs,
  *   - d_kps, d_desc and d_n_out must not be read, written or freed: they are written last, by
  *     the descriptor stage, on a stream of its own.
  * Work the caller enqueues on streams of its own is not ordered against the batch: synchronise
- * the context first.  Several batches may be enqueued back to back with sync = 0 (each with its
- * own output arrays); they run in order and overlap where their stages allow. */
+ * it first.  In particular d_imgs must be complete in device memory when the call is made,
+ * unless an orbx_* call on this context produced it (orbx_gray_batch_device,
+ * orbx_remap_batch_device: those are ordered in front of the batch).  The library relies on
+ * that: a batch of resident images builds its pyramid as soon as the arenas are free, which
+ * may be before the previous batch has been detected.  Several batches may be enqueued back to
+ * back with sync = 0 (each with its own output arrays); their results are those of the same
+ * calls made one at a time, and their stages overlap where they allow. */
 int orbx_extract_batch_device(orbx_ctx* ctx, int n, const uint8_t* d_imgs, int width, int height,
                               int stride, size_t frame_stride, orbx_kp* d_kps, int kp_cap,
                               uint8_t* d_desc, int32_t* d_n_out, int sync);
