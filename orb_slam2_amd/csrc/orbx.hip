@@ -641,7 +641,11 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     // kernel on the main stream, or the main stream holds reads of the arenas) is ordered the other way: pyramid
     // behind the main stream's position, blur behind FAST.  Measured on 512-frame batches enqueued back to back:
     // 1.94 -> 1.87 ms per batch; with the blur moved up but the pyramid still behind the main stream, 1.96 ms.
+#ifdef ORBX_DIAG_BREAK_ORDER  // diagnostic build: the ordering tests must fail on it
+    const bool free_run = overlap && inputs_at_call && !c->dbg_ordered;
+#else
     const bool free_run = overlap && inputs_at_call && !c->main_touched && !c->dbg_ordered;
+#endif
     const bool pipeline_busy = c->desc_pending[0] || c->desc_pending[1];
     // A quadtree of 1024-thread workgroups with the node tables of a level of more than a thousand features in LDS (4K
     // frames: most of a CU's 160 KB) finds no room on a CU while FAST's four-wave, 18 KB workgroups keep arriving:
