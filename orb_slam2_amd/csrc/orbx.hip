@@ -609,7 +609,18 @@ int ensure_aux_streams(orbx_ctx* c) {
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_desc[0], hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_desc[1], hipEventDisableTiming));
     for (int i = 0; i < kArenaSets; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_arena[i], hipEventDisableTiming));
+#ifdef ORBX_DIAG_FOUR_STREAMS  // diagnostic build: the quadtree on a stream of its own, as up to round 3
     HIP_TRY(c, hipStreamCreateWithFlags(&c->st_oct, hipStreamNonBlocking));
+#else
+    // The quadtree shares the descriptor stream.  A process has four hardware queues, one of them the null stream's;
+    // with a fourth compute stream two of the context's streams share a queue, the runtime picks which, and kernels
+    // on one queue run strictly one after the other.  The first context of a process got the quadtree and the
+    // descriptors together (harmless: a batch's descriptors wait for its quadtree anyway), a context created after
+    // another one had been destroyed got FAST and the quadtree together and ran every batch 5 % slower (10 % on 4K
+    // frames).  With three streams every one has a queue to itself whatever the process did before, and the
+    // quadtree and the descriptors are ordered the way the lucky mapping ordered them.
+    c->st_oct = c->st_desc;
+#endif
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_oct_set[0], hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_oct_set[1], hipEventDisableTiming));
     c->aux_made = true;
@@ -625,10 +636,10 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
     c->kp_set = kp_set;
     const int L = c->tab.nlevels;
     BatchDev& B = c->B;
-    // Three streams.  The main stream runs FAST on level 0 (which needs no pyramid) at once, FAST on
-    // the other levels when the pyramid is there, and the quadtree.  The auxiliary
-    // stream builds the pyramid and blurs it.  The descriptor stream runs the last stage once the
-    // quadtree and the blur have finished.  The memory-bound pyramid and blur so fill what the
+    // Three streams.  The main stream runs FAST: on level 0 (which needs no pyramid) at once and on
+    // the other levels when the pyramid is there, or in one launch (below).  The auxiliary
+    // stream builds the pyramid and blurs it.  The descriptor stream runs the quadtree once FAST has
+    // finished and the last stage once the blur has finished too.  The memory-bound pyramid and blur so fill what the
     // VALU-bound FAST and the latency-bound quadtree leave idle, and the next batch, which works in
     // the other set of arenas, is detected while this one is described.
     // The no-overlap switch (ORBX_NO_OVERLAP=1) puts everything on the main stream in stage order.
@@ -787,7 +798,7 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
         if ((rc = mark(kEvBlur1, aux))) return rc;
         HIP_TRY(c, hipEventRecord(c->ev_blur_done, aux));
     }
-    // stage 2: quadtree retention, on a stream of its own so that the next batch's FAST (which writes the other
+    // stage 2: quadtree retention, off the main stream so that the next batch's FAST (which writes the other
     // set of candidate lists) starts beside it: the quadtree is bound by latency and leaves the vector units to
     // FAST.  It overwrites the retained points of set kp_set, which the descriptor stage of the batch before the
     // previous one may still be reading.
@@ -823,7 +834,7 @@ int run_batch(orbx_ctx* c, int n, const uint8_t* l0, int l0_pitch, size_t l0_pla
         HIP_TRY(c, hipEventRecord(c->ev_oct_done, so));
         HIP_TRY(c, hipEventRecord(c->ev_oct_set[kp_set], so));
         c->oct_pending[kp_set] = true;
-        HIP_TRY(c, hipStreamWaitEvent(sd, c->ev_oct_done, 0));
+        if (sd != so) HIP_TRY(c, hipStreamWaitEvent(sd, c->ev_oct_done, 0));  // (one stream: already in order)
         HIP_TRY(c, hipStreamWaitEvent(sd, c->ev_blur_done, 0));
     } else {
         if ((rc = mark(kEvBlur0, st))) return rc;
@@ -1437,7 +1448,7 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
         for (int i = 0; i < kArenaSets; ++i) (void)hipEventDestroy(c->ev_arena[i]);
         (void)hipEventDestroy(c->ev_oct_set[0]);
         (void)hipEventDestroy(c->ev_oct_set[1]);
-        (void)hipStreamDestroy(c->st_oct);
+        if (c->st_oct != c->st_desc) (void)hipStreamDestroy(c->st_oct);
         (void)hipStreamDestroy(c->st_desc);
         (void)hipStreamDestroy(c->st_aux);
     }
