@@ -609,7 +609,7 @@ int ensure_aux_streams(orbx_ctx* c) {
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_desc[0], hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_desc[1], hipEventDisableTiming));
     for (int i = 0; i < kArenaSets; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_arena[i], hipEventDisableTiming));
-#ifdef ORBX_DIAG_FOUR_STREAMS  // diagnostic build: the quadtree on a stream of its own, as up to round 3
+#ifdef ORBX_DIAG_FOUR_STREAMS  // diagnostic build: the quadtree on a fourth stream of its own (the layout the comment below describes the cost of)
     HIP_TRY(c, hipStreamCreateWithFlags(&c->st_oct, hipStreamNonBlocking));
 #else
     // The quadtree shares the descriptor stream.  A process has four hardware queues, one of them the null stream's;
