@@ -146,7 +146,10 @@ __host__ __device__ inline FastLds fast_lds_need(int wd, int hd, int nc) {
 }
 
 constexpr int kFastFixedPitch = 160;  // fits tiles up to 131 detection columns (four cells of up to 32 pixels, or three of up to 43)
-constexpr int kFastStageDepth = 3;  // 16-byte loads in flight per thread while staging a tile
+#ifndef ORBX_FAST_STAGE_DEPTH
+#define ORBX_FAST_STAGE_DEPTH 2  // 16-byte loads in flight per thread while staging a tile: a tile of four cells is 380 chunks, two per thread at most (3: 1.3 % slower, the third slot is address arithmetic for nothing; 4: 0.5 % slower)
+#endif
+constexpr int kFastStageDepth = ORBX_FAST_STAGE_DEPTH;  // 16-byte loads in flight per thread while staging a tile
 
 // Diagnostic build only (-DORBX_STAMPS): wave 0 adds the cycles between phase boundaries into
 // B.stamps[phase] (1024 copies, spread by block id, to keep the atomics off one address); the product build compiles these calls away.
