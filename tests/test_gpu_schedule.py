@@ -37,6 +37,7 @@ class _Seq:
         self.ops[0] = "batch"
         self.ops[3] = self.ops[9] = "gray"
         self.src = [int(rng.integers(0, 4)) for _ in range(length)]
+        self.frames = [int(rng.choice([N, N, N // 2, 8])) for _ in range(length)]   # batches of different sizes in one sequence
 
     def run(self, wait):
         """Returns the list of everything the sequence produced, in order."""
@@ -44,22 +45,25 @@ class _Seq:
         outs, res, keep = [], [], []
         self.conv.fill(0)
         n_gray = 0
+        last_n = N
         # every buffer is allocated and cleared before the first call: clearing one synchronises the device
         pool = [(DA((N, cap, 28), np.uint8, fill_byte=0), DA((N, cap, 32), np.uint8, fill_byte=0), DA((N,), np.int32, fill_byte=0))
                 for op in self.ops if op in ("batch", "odd", "gray")]
         spool = [(DA((N // 2, cap), np.float32, fill_byte=0), DA((N // 2, cap), np.float32, fill_byte=0))
                  for op in self.ops if op == "stereo"]
 
-        def batch(ptr, stride):
+        def batch(ptr, stride, n=N):
+            nonlocal last_n
+            last_n = n
             o = pool[len(outs)]
             outs.append(o)
-            ex.extract_batch_device(ptr, N, W, H, stride, H * stride, o[0].ptr, cap, o[1].ptr, o[2].ptr, sync=wait)
+            ex.extract_batch_device(ptr, n, W, H, stride, H * stride, o[0].ptr, cap, o[1].ptr, o[2].ptr, sync=wait)
 
-        for op, s in zip(self.ops, self.src):
+        for op, s, nfr in zip(self.ops, self.src, self.frames):
             if op == "batch":
-                batch(self.inputs[s].ptr, W)
+                batch(self.inputs[s].ptr, W, nfr)
             elif op == "odd":
-                batch(self.odd.ptr, W + 3)
+                batch(self.odd.ptr, W + 3, nfr)
             elif op == "gray":                                   # the batch reads what the kernel in front of it writes
                 ex.gray_batch_device(N, self.rgb[n_gray & 1].ptr, W, H, 3 * W, 3 * W * H, 3, 0, self.conv.ptr, W, W * H, sync=wait)
                 n_gray += 1
@@ -68,9 +72,9 @@ class _Seq:
                 k, q, c = outs[-1]
                 u, z = spool[len(keep)]
                 keep.append((u, z))
-                ex.stereo_match_batch_device(N // 2, k.ptr, cap, q.ptr, c.ptr, 0.5, 300.0, u.ptr, z.ptr, sync=wait)
+                ex.stereo_match_batch_device(last_n // 2, k.ptr, cap, q.ptr, c.ptr, 0.5, 300.0, u.ptr, z.ptr, sync=wait)
             elif op == "level":                                  # a read-back (synchronises) of the last batch's pyramid
-                res.append(ex.pyramid_level(N - 1, NL - 1).copy())
+                res.append(ex.pyramid_level(last_n - 1, NL - 1).copy())
             elif op == "sync":
                 ex.synchronize()
         ex.synchronize()
@@ -102,6 +106,6 @@ def test_random_call_sequences_without_waiting(seed):
             for i, (a, b) in enumerate(zip(ref, got)):
                 assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), (seed, ordered, rep, i, seq.ops)
     counts = [r for r in ref if r.dtype == np.int32 and r.shape == (N,)]
-    assert counts and all((c > 0).all() for c in counts)          # the frames do hold features: the comparison is not empty
+    assert counts and all(c[:8].min() > 0 for c in counts)        # the frames do hold features: the comparison is not empty
     seq.free()
     ex.close()
